@@ -1,0 +1,207 @@
+/*
+ * kdf.h -- C ABI of the MI355X-native canonical k-mer count / filter / probe
+ * engine (libkdf.so).  This is the drop-in boundary for the one hot path of
+ * jlanej/kmer_denovo_filter; every entry point names the reference interface
+ * it replaces (file:line relative to the reference repository root).
+ *
+ * The reference has no FFI: the path sits behind Python helper functions that
+ * spawn `samtools fasta | jellyfish count [-C --if] ; jellyfish dump/query`.
+ * A maintainer binds this header with ctypes (INTEGRATION.md shows the stub);
+ * kmer_denovo_filter_amd/_native.py is that binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross the boundary.
+ *   - every function returns 0 on success or a KDF_ERR_* code; the message is
+ *     kdf_last_error(h) (or kdf_last_error(NULL) for create/IO failures).
+ *     The Python mirror raises RuntimeError, matching the reference's
+ *     RuntimeError("jellyfish ... failed: ...") convention
+ *     (core/jellyfish_wrappers.py:239-242, discovery/pipeline.py:168-172).
+ *   - the caller owns host buffers; the engine owns device memory.
+ *   - one engine = one GPU = one table; a handle is not thread-safe.
+ *   - keys are canonical k-mers in the Jellyfish encoding: 2 bits per base,
+ *     A=0 C=1 G=2 T=3, leftmost base most significant, canonical = numeric min
+ *     of the k-mer and its reverse complement (== kmer_utils.canonicalize,
+ *     src/kmer_denovo_filter/kmer_utils.py:35-38).  k <= 32: one uint64 (lo);
+ *     33 <= k <= 63: (lo, hi) pair.  `hi` arrays may be NULL when k <= 32.
+ *
+ * Read streams
+ *   Reads are handed over as ONE 2-bit-packed base stream plus a 1-bit
+ *   "invalid" mask.  Base i lives in bits 2*(i%32) of packed[i/32]; bit (i%64)
+ *   of invalid[i/64] is set when position i is not A/C/G/T (N, IUPAC) or is the
+ *   single separator position that kdf_pack_reads() inserts after every read,
+ *   so that no window spans two records (Jellyfish: windows never span FASTA
+ *   records).  A window [i, i+k) is counted iff none of its k positions is
+ *   invalid.  This keeps the kernels free of per-read bookkeeping and load
+ *   balanced for ragged reads.
+ */
+#ifndef KDF_H
+#define KDF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KDF_OK               0
+#define KDF_ERR_INVALID      1   /* bad argument (k out of range, NULL pointer ...) */
+#define KDF_ERR_HIP          2   /* HIP runtime error; message carries hipGetErrorString */
+#define KDF_ERR_NOMEM        3   /* host or device allocation failed */
+#define KDF_ERR_TABLE_FULL   4   /* a bucket overflowed: never silent, grow and redo */
+#define KDF_ERR_IO           5   /* file open/read/format error (BAM/FASTA/.jf) */
+#define KDF_ERR_STATE        6   /* call not valid in the engine's current mode */
+
+typedef struct kdf_engine kdf_engine;
+typedef struct kdf_reader kdf_reader;
+
+/* ---------------------------------------------------------------- engine -- */
+
+/* Create an engine on HIP device `device` for k-mers of length k (1..63) with
+ * room for at least capacity_hint distinct keys before the first grow.
+ * Replaces the process launch + `-m k -s SIZE` of `jellyfish count`
+ * (core/jellyfish_wrappers.py:167-176,313-321; discovery/pipeline.py:114-122). */
+int kdf_create(int device, int k, uint64_t capacity_hint, kdf_engine **out);
+void kdf_destroy(kdf_engine *h);
+const char *kdf_last_error(const kdf_engine *h);
+
+/* Use an externally created hipStream_t (e.g. torch's current stream) for all
+ * subsequent launches; NULL restores the engine's own stream. */
+int kdf_set_stream(kdf_engine *h, void *hip_stream);
+int kdf_synchronize(kdf_engine *h);
+
+/* Empty the table (all keys and counts dropped). */
+int kdf_clear(kdf_engine *h);
+/* Make room for at least n_keys distinct keys (rehashes the live entries). */
+int kdf_reserve(kdf_engine *h, uint64_t n_keys);
+/* capacity in slots, distinct keys currently stored, valid windows processed
+ * by the count calls since the last clear.  Any pointer may be NULL. */
+int kdf_stats(kdf_engine *h, uint64_t *capacity, uint64_t *distinct, uint64_t *windows);
+
+/* ------------------------------------------------- count (insert) stage -- */
+
+/* `jellyfish count -m k -C` over a read stream: every valid window's canonical
+ * k-mer is inserted / incremented (saturating uint32, like Jellyfish's 4-byte
+ * output counter).  Replaces the counting half of
+ * _extract_child_kmers_discovery (discovery/pipeline.py:114-172) and of
+ * _ensure_ref_jf (core/jellyfish_wrappers.py:313-326).  Host buffers. */
+int kdf_count_reads(kdf_engine *h, const uint64_t *packed, const uint64_t *invalid,
+                    uint64_t n_bases);
+/* Same with the stream already resident in HBM (device pointers, padded as
+ * kdf_stream_words() says). */
+int kdf_count_reads_dev(kdf_engine *h, const void *d_packed, const void *d_invalid,
+                        uint64_t n_bases);
+
+/* ------------------------------------------------ count --if (filter) ---- */
+
+/* Load the `--if` filter: the table becomes exactly these canonical keys with
+ * count 0 (core/jellyfish_wrappers.py:173, discovery/pipeline.py:383).  Keys
+ * must already be canonical (the reference's filter files are). */
+int kdf_load_filter(kdf_engine *h, const uint64_t *keys_lo, const uint64_t *keys_hi,
+                    uint64_t n);
+/* `jellyfish count -C --if`: only windows whose canonical k-mer is in the table
+ * are counted; nothing is inserted.  Replaces _scan_parent_jellyfish
+ * (core/jellyfish_wrappers.py:115-283) and _count_parent_jellyfish
+ * (discovery/pipeline.py:322-459). */
+int kdf_count_reads_filtered(kdf_engine *h, const uint64_t *packed,
+                             const uint64_t *invalid, uint64_t n_bases);
+int kdf_count_reads_filtered_dev(kdf_engine *h, const void *d_packed,
+                                 const void *d_invalid, uint64_t n_bases);
+
+/* ------------------------------------------------------- query / dump ---- */
+
+/* `jellyfish query idx -s kmers.fa`: counts_out[i] = count of key i, 0 when
+ * absent, INPUT ORDER (discovery/pipeline.py:286-304,515-532,565-583;
+ * kmer_utils.py:152-183). */
+int kdf_query(kdf_engine *h, const uint64_t *keys_lo, const uint64_t *keys_hi,
+              uint64_t n, uint32_t *counts_out);
+/* device-pointer form: d_counts_out can be a torch tensor that is then
+ * all-reduced over RCCL (multi-GPU merge of per-rank filter counts). */
+int kdf_query_dev(kdf_engine *h, const void *d_keys_lo, const void *d_keys_hi,
+                  uint64_t n, void *d_counts_out);
+
+/* `jellyfish dump -c -L min_count`: number of entries with count >= min_count
+ * (min_count = 0 returns every stored key, counts 0 included). */
+int kdf_count_ge(kdf_engine *h, uint32_t min_count, uint64_t *n_out);
+/* ... and the entries themselves, ASCENDING key order (deterministic; the
+ * reference does not rely on Jellyfish's hash order).  cap = room in the out
+ * arrays; *n_out = entries written.  keys_hi_out / counts_out may be NULL.
+ * (discovery/pipeline.py:207-226; core/jellyfish_wrappers.py:262-272) */
+int kdf_export_ge(kdf_engine *h, uint32_t min_count, uint64_t *keys_lo_out,
+                  uint64_t *keys_hi_out, uint32_t *counts_out, uint64_t cap,
+                  uint64_t *n_out);
+
+/* ------------------------------------------------------ Module-3 scan ---- */
+
+/* Probe every window of a read stream against the table: bit i of hit_bits is
+ * set iff window i is valid and its canonical k-mer is stored with count > 0
+ * (JellyfishKmerQuery: parts[1] != "0", kmer_utils.py:181).  hit_bits has
+ * kdf_stream_words()' invalid-word count of uint64 words.
+ * When read_offsets != NULL (n_reads+1 stream offsets of the read starts, as
+ * kdf_pack_reads() returns them) distinct_out[r] = number of DISTINCT canonical
+ * k-mers hit in read r (len(unique_in_read), core/bam_scanner.py:435-442).
+ * Replaces the inner loop of _scan_contig_for_hits (core/bam_scanner.py:396-474)
+ * and JellyfishKmerQuery.scan_read (kmer_utils.py:209-238). */
+int kdf_scan_reads(kdf_engine *h, const uint64_t *packed, const uint64_t *invalid,
+                   uint64_t n_bases, const int64_t *read_offsets, int64_t n_reads,
+                   uint64_t *hit_bits, uint32_t *distinct_out);
+int kdf_scan_reads_dev(kdf_engine *h, const void *d_packed, const void *d_invalid,
+                       uint64_t n_bases, void *d_hit_bits);
+
+/* ------------------------------------------------------- host utilities -- */
+
+/* Words a stream of n_bases needs (padding included): the packed array must
+ * hold *packed_words uint64, the invalid / hit arrays *mask_words uint64. */
+void kdf_stream_words(uint64_t n_bases, uint64_t *packed_words, uint64_t *mask_words);
+
+/* Pack ASCII records (A/C/G/T any case; everything else invalid) into a stream
+ * with one separator after each record.  offsets[n_reads+1] delimit the records
+ * in `ascii`.  stream_offsets_out[n_reads+1] (may be NULL) receives each
+ * record's start in the stream (record r occupies [so[r], so[r]+len_r); the
+ * last entry is n_bases).  Stream length = sum(len) + n_reads.
+ * Restates what `samtools fasta` hands to Jellyfish (one FASTA record per read). */
+int kdf_pack_reads(const char *ascii, const int64_t *offsets, int64_t n_reads,
+                   uint64_t *packed_out, uint64_t *invalid_out,
+                   int64_t *stream_offsets_out, uint64_t *n_bases_out);
+
+/* Canonical key of one ASCII k-mer; returns KDF_ERR_INVALID on a non-ACGT byte
+ * (kmer_utils.py:35-38). */
+int kdf_canonical(const char *kmer, int k, uint64_t *lo, uint64_t *hi);
+
+/* ------------------------------------------------- BAM / FASTA feeders ---- */
+
+/* Streaming BAM reader with `samtools fasta -F flag_off` semantics
+ * (core/jellyfish_wrappers.py:159-165, discovery/pipeline.py:106-112): records
+ * with any flag_off bit are dropped; when collapse != 0 each run of consecutive
+ * same-QNAME records yields at most one record per read part (READ1 / READ2 /
+ * other), a record with qualities beating one without, first wins.
+ * collapse = 0, flag_off = 0x500 gives Module 3's pysam iteration
+ * (core/bam_scanner.py:405-409: skip SECONDARY and DUPLICATE, keep the rest). */
+int kdf_bam_open(const char *path, uint32_t flag_off, int collapse, int threads,
+                 kdf_reader **out);
+/* Multi-record FASTA (reference genome, plain or gzip) as a reader: one stream
+ * record per sequence, any case, non-ACGT invalid.  A sequence longer than a
+ * batch is continued in the next batch k-1 bases back, so no window is lost or
+ * counted twice.  Replaces Jellyfish's own FASTA parsing in _ensure_ref_jf
+ * (core/jellyfish_wrappers.py:313-321). */
+int kdf_fasta_open(const char *path, int k, kdf_reader **out);
+/* Fill up to max_bases stream positions / max_reads records.  Returns the batch
+ * through the out pointers; *n_reads_out = 0 at end of file.  packed_out /
+ * invalid_out must hold kdf_stream_words(max_bases) words;
+ * stream_offsets_out max_reads+1 entries.  A record longer than max_bases is an
+ * error (KDF_ERR_INVALID). */
+int kdf_reader_next(kdf_reader *r, uint64_t max_bases, int64_t max_reads,
+                    uint64_t *packed_out, uint64_t *invalid_out,
+                    int64_t *stream_offsets_out, int64_t *n_reads_out,
+                    uint64_t *n_bases_out);
+/* Per-record metadata of the LAST batch (BAM readers; arrays of n_reads):
+ * flag, ref_id, pos, and the offsets of NUL-terminated names in name_buf. */
+int kdf_reader_last_meta(kdf_reader *r, const uint16_t **flags, const int32_t **ref_ids,
+                         const int32_t **positions, const char **name_buf,
+                         const int64_t **name_offsets);
+void kdf_reader_close(kdf_reader *r);
+const char *kdf_reader_error(const kdf_reader *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KDF_H */

@@ -1,0 +1,98 @@
+"""ctypes binding of include/kdf.h (libkdf.so).
+
+This is the stub a maintainer of the reference would add.
+There is no CPU fallback: if the library is missing or no GPU is visible the
+calls raise, loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_int, c_int32, c_int64, c_uint16, c_uint32, c_uint64, c_void_p
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libkdf.so")
+
+KDF_OK = 0
+KDF_ERR_INVALID, KDF_ERR_HIP, KDF_ERR_NOMEM, KDF_ERR_TABLE_FULL, KDF_ERR_IO, KDF_ERR_STATE = 1, 2, 3, 4, 5, 6
+
+# every symbol include/kdf.h declares: (name, restype, argtypes)
+_P = c_void_p
+SYMBOLS = [
+    ("kdf_create", c_int, [c_int, c_int, c_uint64, POINTER(_P)]),
+    ("kdf_destroy", None, [_P]),
+    ("kdf_last_error", c_char_p, [_P]),
+    ("kdf_set_stream", c_int, [_P, _P]),
+    ("kdf_synchronize", c_int, [_P]),
+    ("kdf_clear", c_int, [_P]),
+    ("kdf_reserve", c_int, [_P, c_uint64]),
+    ("kdf_stats", c_int, [_P, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
+    ("kdf_count_reads", c_int, [_P, _P, _P, c_uint64]),
+    ("kdf_count_reads_dev", c_int, [_P, _P, _P, c_uint64]),
+    ("kdf_load_filter", c_int, [_P, _P, _P, c_uint64]),
+    ("kdf_count_reads_filtered", c_int, [_P, _P, _P, c_uint64]),
+    ("kdf_count_reads_filtered_dev", c_int, [_P, _P, _P, c_uint64]),
+    ("kdf_query", c_int, [_P, _P, _P, c_uint64, _P]),
+    ("kdf_query_dev", c_int, [_P, _P, _P, c_uint64, _P]),
+    ("kdf_count_ge", c_int, [_P, c_uint32, POINTER(c_uint64)]),
+    ("kdf_export_ge", c_int, [_P, c_uint32, _P, _P, _P, c_uint64, POINTER(c_uint64)]),
+    ("kdf_scan_reads", c_int, [_P, _P, _P, c_uint64, _P, c_int64, _P, _P]),
+    ("kdf_scan_reads_dev", c_int, [_P, _P, _P, c_uint64, _P]),
+    ("kdf_stream_words", None, [c_uint64, POINTER(c_uint64), POINTER(c_uint64)]),
+    ("kdf_pack_reads", c_int, [_P, _P, c_int64, _P, _P, _P, POINTER(c_uint64)]),
+    ("kdf_canonical", c_int, [c_char_p, c_int, POINTER(c_uint64), POINTER(c_uint64)]),
+    ("kdf_bam_open", c_int, [c_char_p, c_uint32, c_int, c_int, POINTER(_P)]),
+    ("kdf_fasta_open", c_int, [c_char_p, c_int, POINTER(_P)]),
+    ("kdf_reader_next", c_int, [_P, c_uint64, c_int64, _P, _P, _P, POINTER(c_int64), POINTER(c_uint64)]),
+    ("kdf_reader_last_meta", c_int, [_P, POINTER(POINTER(c_uint16)), POINTER(POINTER(c_int32)),
+                                     POINTER(POINTER(c_int32)), POINTER(c_char_p), POINTER(POINTER(c_int64))]),
+    ("kdf_reader_close", None, [_P]),
+    ("kdf_reader_error", c_char_p, [_P]),
+]
+
+_lib = None
+
+
+class KdfError(RuntimeError):
+    """Engine failure; mirrors the reference's RuntimeError("jellyfish ... failed: ...")."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"kdf engine failed ({code}): {msg}")
+        self.code = code
+
+
+def load() -> ctypes.CDLL:
+    """Load libkdf.so, building it first if the source tree has hipcc and no .so."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from .build import build_native
+        try:
+            build_native()
+        except Exception as e:  # noqa: BLE001
+            raise ImportError(
+                f"libkdf.so is not built ({LIB_PATH}) and building it failed: {e}. "
+                "Run `python -m kmer_denovo_filter_amd.build`. There is no CPU fallback."
+            ) from e
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, handle=None):
+    if rc != KDF_OK:
+        lib = load()
+        msg = lib.kdf_last_error(handle)
+        raise KdfError(rc, msg.decode(errors="replace") if msg else "unknown error")
+
+
+def check_reader(rc: int, reader=None):
+    if rc != KDF_OK:
+        lib = load()
+        msg = lib.kdf_reader_error(reader)
+        raise KdfError(rc, msg.decode(errors="replace") if msg else "unknown error")

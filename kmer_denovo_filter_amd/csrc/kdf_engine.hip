@@ -1,0 +1,736 @@
+// kdf_engine.hip -- libkdf.so: HIP kernels (gfx950) + engine + the C ABI of
+// include/kdf.h.  See DESIGN.md for the data layout and the roofline of each
+// kernel.  No CPU fallback exists in this library: every entry point either
+// runs on the GPU or returns an error.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kdf.h"
+#include "kdf_device.h"
+
+// sorted export lives in kdf_sort.hip (rocPRIM radix sort)
+int kdf_sort_pairs_device(uint64_t *d_lo, uint64_t *d_hi, uint32_t *d_cnt, uint64_t n,
+                          hipStream_t stream, std::string &err);
+
+// ===========================================================================
+// kernels
+// ===========================================================================
+
+enum { MODE_INSERT = 0, MODE_FILTERED = 1, MODE_SCAN = 2 };
+
+// One thread = one tile of 64 window starts.  Windows are processed in batches
+// of 8: the 8 home-slot key loads are issued back to back before any of them is
+// resolved, so a wave keeps 8 x 64 random HBM reads in flight.
+template <int KW, int MODE>
+__global__ __launch_bounds__(256) void kdf_stream_kernel(
+    const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid,
+    uint64_t tile0, uint64_t n_tiles, int k, KdfTable t, KdfCtl *ctl,
+    uint64_t *__restrict__ hit_bits)
+{
+    const uint64_t tile = tile0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = tile < tile0 + n_tiles;
+    uint32_t claimed = 0, nwin = 0;
+    bool full = false;
+    if (active) {
+        const uint64_t m0 = invalid[tile], m1 = invalid[tile + 1];
+        const uint64_t valid = kdf_valid_windows(m0, m1, k);
+        nwin = __popcll(valid);
+        uint64_t hits = 0;
+        if (valid) {
+            constexpr int NW = KW == 1 ? 3 : 4;
+            uint64_t w[NW];
+#pragma unroll
+            for (int i = 0; i < NW; ++i) w[i] = packed[tile * 2 + i];
+            const uint64_t kmask = (k >= 32) ? ~0ull : ((1ull << (2 * k)) - 1);
+#pragma unroll
+            for (int b = 0; b < KDF_TILE; b += 8) {
+                if (((valid >> b) & 0xFF) == 0) continue;
+                uint64_t klo[8], khi[8], slot[8], cur[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if constexpr (KW == 1) {
+                        klo[u] = kdf_window_narrow((const uint64_t (&)[3])w, b + u, k, kmask);
+                        khi[u] = 0;
+                    } else {
+                        kdf_window_wide((const uint64_t (&)[4])w, b + u, k, klo[u], khi[u]);
+                    }
+                    slot[u] = kdf_home(t, kdf_hash(klo[u], khi[u]));
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool ok = (valid >> (b + u)) & 1;
+                    if constexpr (KW == 1) cur[u] = ok ? t.lo[slot[u]] : 0;
+                    else cur[u] = 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool ok = (valid >> (b + u)) & 1;
+                    if (!ok) continue;
+                    if constexpr (MODE == MODE_SCAN) {
+                        uint64_t s = KW == 1 ? kdf_find_narrow(t, klo[u]) : kdf_find_wide(t, klo[u], khi[u]);
+                        if (s != ~0ull && t.cnt[s] != 0) hits |= 1ull << (b + u);
+                    } else if constexpr (KW == 1) {
+                        if (!kdf_add_narrow<MODE == MODE_INSERT>(t, klo[u], 1u, slot[u], cur[u], claimed)) full = true;
+                    } else {
+                        if (!kdf_add_wide<MODE == MODE_INSERT>(t, klo[u], khi[u], 1u, slot[u], claimed)) full = true;
+                    }
+                }
+            }
+        }
+        if constexpr (MODE == MODE_SCAN) hit_bits[tile] = hits;
+    }
+    if (full) atomicOr(&ctl->error, 1u);
+    // statistics: wave-reduce, one atomic per wave into a sharded counter
+    uint32_t c = claimed, n = nwin;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { c += __shfl_down(c, o); n += __shfl_down(n, o); }
+    if ((threadIdx.x & 63) == 0) {
+        const int shard = (blockIdx.x * 4 + (threadIdx.x >> 6)) % KDF_SHARDS;
+        if (c) atomicAdd(&ctl->distinct[shard * 16], (unsigned long long)c);
+        if (n) atomicAdd(&ctl->windows[shard * 16], (unsigned long long)n);
+    }
+}
+
+// thread per key: insert with an explicit add (filter load: add = 0; rehash: add = count)
+template <int KW>
+__global__ __launch_bounds__(256) void kdf_insert_keys_kernel(
+    const uint64_t *__restrict__ klo, const uint64_t *__restrict__ khi,
+    const uint32_t *__restrict__ add, uint64_t n, KdfTable t, KdfCtl *ctl, int skip_empty)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t claimed = 0;
+    bool full = false;
+    if (i < n) {
+        const uint64_t lo = klo[i], hi = KW == 2 ? khi[i] : 0;
+        const bool present = KW == 1 ? (lo != KDF_EMPTY) : (hi != KDF_EMPTY);
+        if (present || !skip_empty) {
+            const uint32_t a = add ? add[i] : 0u;
+            const uint64_t slot = kdf_home(t, kdf_hash(lo, hi));
+            if constexpr (KW == 1) {
+                if (!kdf_add_narrow<true>(t, lo, a, slot, t.lo[slot], claimed)) full = true;
+            } else {
+                if (!kdf_add_wide<true>(t, lo, hi & ~KDF_PENDING, a, slot, claimed)) full = true;
+            }
+        }
+    }
+    if (full) atomicOr(&ctl->error, 1u);
+    uint32_t c = claimed;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0 && c)
+        atomicAdd(&ctl->distinct[((blockIdx.x * 4 + (threadIdx.x >> 6)) % KDF_SHARDS) * 16],
+                  (unsigned long long)c);
+}
+
+template <int KW>
+__global__ __launch_bounds__(256) void kdf_query_kernel(
+    const uint64_t *__restrict__ klo, const uint64_t *__restrict__ khi, uint64_t n,
+    KdfTable t, uint32_t *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t s = KW == 1 ? kdf_find_narrow(t, klo[i]) : kdf_find_wide(t, klo[i], khi[i]);
+    out[i] = (s == ~0ull) ? 0u : t.cnt[s];
+}
+
+// dump -L: count / append entries with cnt >= min_count.  Append positions are
+// reserved per wave (ballot + one atomic), so a wave's entries are contiguous.
+template <int KW, bool WRITE>
+__global__ __launch_bounds__(256) void kdf_export_kernel(
+    KdfTable t, uint32_t min_count, KdfCtl *ctl, uint64_t *__restrict__ olo,
+    uint64_t *__restrict__ ohi, uint32_t *__restrict__ ocnt, uint64_t out_cap)
+{
+    const uint64_t cap = 1ull << t.log2cap;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool keep = false;
+    uint64_t lo = 0, hi = 0; uint32_t c = 0;
+    if (i < cap) {
+        lo = t.lo[i];
+        if (KW == 2) hi = t.hi[i];
+        const bool occ = KW == 1 ? (lo != KDF_EMPTY) : (hi != KDF_EMPTY);
+        c = t.cnt[i];
+        keep = occ && c >= min_count;
+    }
+    const unsigned long long b = __ballot(keep);
+    if (b == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int n = __popcll(b);
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&ctl->cursor, (unsigned long long)n);
+    base = __shfl(base, 0);
+    if (WRITE && keep) {
+        const uint64_t pos = base + __popcll(b & ((1ull << lane) - 1));
+        if (pos < out_cap) {
+            olo[pos] = lo;
+            if (KW == 2 && ohi) ohi[pos] = hi;
+            if (ocnt) ocnt[pos] = c;
+        }
+    }
+}
+
+__global__ void kdf_ctl_reduce_kernel(KdfCtl *ctl, unsigned long long *out3) {
+    // out3 = {distinct, windows, error}; single wave
+    unsigned long long d = ctl->distinct[threadIdx.x * 16], w = ctl->windows[threadIdx.x * 16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { d += __shfl_down(d, o); w += __shfl_down(w, o); }
+    if (threadIdx.x == 0) { out3[0] = d; out3[1] = w; out3[2] = ctl->error; out3[3] = ctl->cursor; }
+}
+
+// ===========================================================================
+// engine
+// ===========================================================================
+
+struct kdf_engine {
+    int device = 0;
+    int k = 0;
+    int kw = 1;
+    KdfTable t{};                 // live table
+    uint64_t cap = 0;
+    KdfCtl *ctl = nullptr;        // device
+    unsigned long long *d_out4 = nullptr;   // device scratch for ctl readback
+    unsigned long long *h_out4 = nullptr;   // pinned host mirror
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    uint64_t distinct = 0;        // host mirror after the last sync
+    uint64_t windows = 0;
+    bool filter_mode = false;
+    // grow-only device staging for the host-buffer entry points
+    void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t stage_bytes[4] = {0, 0, 0, 0};
+    std::string err;
+};
+
+static thread_local std::string g_err;
+
+static int fail(kdf_engine *h, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (h) h->err = buf; else g_err = buf;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                 \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return fail(h, e_ == hipErrorOutOfMemory ? KDF_ERR_NOMEM : KDF_ERR_HIP,     \
+                        "%s failed: %s", #call, hipGetErrorString(e_));                 \
+    } while (0)
+
+static uint32_t log2ceil(uint64_t x) { uint32_t l = 0; while ((1ull << l) < x) ++l; return l; }
+
+// slots needed so that n keys sit at load <= 0.5 (narrow: 8192-slot buckets,
+// wide: 4096-slot buckets = what one workgroup can hold in LDS)
+static uint32_t cap_log2_for(uint64_t n_keys) {
+    uint32_t l = log2ceil(std::max<uint64_t>(n_keys, 1) * 2);
+    return std::max<uint32_t>(l, 10);
+}
+
+static int table_alloc(kdf_engine *h, uint32_t log2cap, KdfTable &t) {
+    const uint64_t cap = 1ull << log2cap;
+    t = KdfTable{};
+    t.log2cap = log2cap;
+    t.bucket_bits = std::min<uint32_t>(log2cap, h->kw == 1 ? 13 : 12);
+    HIPCHK(h, hipMalloc((void **)&t.lo, cap * 8));
+    if (h->kw == 2) HIPCHK(h, hipMalloc((void **)&t.hi, cap * 8));
+    HIPCHK(h, hipMalloc((void **)&t.cnt, cap * 4));
+    HIPCHK(h, hipMemsetAsync(t.lo, 0xFF, cap * 8, h->stream));
+    if (h->kw == 2) HIPCHK(h, hipMemsetAsync(t.hi, 0xFF, cap * 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(t.cnt, 0, cap * 4, h->stream));
+    return KDF_OK;
+}
+static void table_free(KdfTable &t) {
+    if (t.lo) (void)hipFree(t.lo);
+    if (t.hi) (void)hipFree(t.hi);
+    if (t.cnt) (void)hipFree(t.cnt);
+    t = KdfTable{};
+}
+
+static int stage_reserve(kdf_engine *h, int i, size_t bytes) {
+    if (h->stage_bytes[i] >= bytes) return KDF_OK;
+    if (h->stage[i]) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->stage[i]); h->stage[i] = nullptr; h->stage_bytes[i] = 0; }
+    size_t want = bytes + bytes / 8 + 4096;
+    HIPCHK(h, hipMalloc(&h->stage[i], want));
+    h->stage_bytes[i] = want;
+    return KDF_OK;
+}
+
+// read distinct / windows / error from the control block (synchronises)
+static int ctl_sync(kdf_engine *h, bool *table_full, uint64_t *cursor = nullptr) {
+    hipLaunchKernelGGL(kdf_ctl_reduce_kernel, dim3(1), dim3(64), 0, h->stream, h->ctl, h->d_out4);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(h->h_out4, h->d_out4, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->distinct = h->h_out4[0];
+    h->windows = h->h_out4[1];
+    if (table_full) *table_full = h->h_out4[2] != 0;
+    if (cursor) *cursor = h->h_out4[3];
+    return KDF_OK;
+}
+
+static int ctl_reset(kdf_engine *h, bool keep_windows) {
+    if (keep_windows) {
+        HIPCHK(h, hipMemsetAsync(h->ctl->distinct, 0, sizeof(h->ctl->distinct), h->stream));
+        HIPCHK(h, hipMemsetAsync(&h->ctl->cursor, 0, 16, h->stream));
+    } else {
+        HIPCHK(h, hipMemsetAsync(h->ctl, 0, sizeof(KdfCtl), h->stream));
+    }
+    return KDF_OK;
+}
+
+template <typename F>
+static int by_width(kdf_engine *h, F &&f) { return h->kw == 1 ? f(std::integral_constant<int, 1>{}) : f(std::integral_constant<int, 2>{}); }
+
+// rehash the live table into one with 2^new_log2 slots
+static int table_rehash(kdf_engine *h, uint32_t new_log2) {
+    KdfTable nt;
+    int rc = table_alloc(h, new_log2, nt);
+    if (rc) { table_free(nt); return rc; }
+    const uint64_t old_cap = h->cap;
+    const uint64_t windows = h->windows;
+    rc = ctl_reset(h, false);
+    if (rc) { table_free(nt); return rc; }
+    const unsigned blocks = (unsigned)((old_cap + 255) / 256);
+    if (h->kw == 1)
+        hipLaunchKernelGGL(kdf_insert_keys_kernel<1>, dim3(blocks), dim3(256), 0, h->stream,
+                           (const uint64_t *)h->t.lo, (const uint64_t *)nullptr, (const uint32_t *)h->t.cnt, old_cap, nt, h->ctl, 1);
+    else
+        hipLaunchKernelGGL(kdf_insert_keys_kernel<2>, dim3(blocks), dim3(256), 0, h->stream,
+                           (const uint64_t *)h->t.lo, (const uint64_t *)h->t.hi, (const uint32_t *)h->t.cnt, old_cap, nt, h->ctl, 1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { table_free(nt); return fail(h, KDF_ERR_HIP, "rehash launch failed: %s", hipGetErrorString(e)); }
+    bool full = false;
+    rc = ctl_sync(h, &full);
+    if (rc) { table_free(nt); return rc; }
+    if (full) { table_free(nt); return fail(h, KDF_ERR_TABLE_FULL, "rehash: bucket overflow at 2^%u slots", new_log2); }
+    table_free(h->t);
+    h->t = nt;
+    h->cap = 1ull << new_log2;
+    // restore the window counter (host-side accumulation)
+    h->windows = windows;
+    HIPCHK(h, hipMemcpyAsync(&h->ctl->windows[0], &h->windows, 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return KDF_OK;
+}
+
+template <int MODE>
+static void launch_stream(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid,
+                          uint64_t tile0, uint64_t n_tiles, uint64_t *d_hits) {
+    const unsigned blocks = (unsigned)((n_tiles + 255) / 256);
+    if (h->kw == 1)
+        hipLaunchKernelGGL((kdf_stream_kernel<1, MODE>), dim3(blocks), dim3(256), 0, h->stream,
+                           d_packed, d_invalid, tile0, n_tiles, h->k, h->t, h->ctl, d_hits);
+    else
+        hipLaunchKernelGGL((kdf_stream_kernel<2, MODE>), dim3(blocks), dim3(256), 0, h->stream,
+                           d_packed, d_invalid, tile0, n_tiles, h->k, h->t, h->ctl, d_hits);
+}
+
+// insert-mode count over a device-resident stream.  The stream is walked in
+// chunks sized so that even if every position were a new key the table stays
+// at load <= 0.8; the table doubles when fewer than cap/8 positions fit.
+static int count_insert_dev(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases) {
+    if (h->filter_mode) return fail(h, KDF_ERR_STATE, "kdf_count_reads: a filter is loaded; call kdf_clear first");
+    const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
+    uint64_t tile = 0;
+    while (tile < n_tiles) {
+        uint64_t room = (h->cap / 10) * 8 > h->distinct ? (h->cap / 10) * 8 - h->distinct : 0;
+        if (room < h->cap / 8) {
+            int rc = table_rehash(h, h->t.log2cap + 1);
+            if (rc) return rc;
+            continue;
+        }
+        uint64_t chunk = std::min<uint64_t>(n_tiles - tile, std::max<uint64_t>(room / KDF_TILE, 1));
+        launch_stream<MODE_INSERT>(h, d_packed, d_invalid, tile, chunk, nullptr);
+        HIPCHK(h, hipGetLastError());
+        bool full = false;
+        int rc = ctl_sync(h, &full);
+        if (rc) return rc;
+        if (full) return fail(h, KDF_ERR_TABLE_FULL, "count: bucket overflow (capacity 2^%u, %llu distinct)",
+                              h->t.log2cap, (unsigned long long)h->distinct);
+        tile += chunk;
+    }
+    return KDF_OK;
+}
+
+static int count_filtered_dev(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases) {
+    if (!h->filter_mode) return fail(h, KDF_ERR_STATE, "kdf_count_reads_filtered: no filter loaded (kdf_load_filter)");
+    const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
+    if (n_tiles == 0) return KDF_OK;
+    launch_stream<MODE_FILTERED>(h, d_packed, d_invalid, 0, n_tiles, nullptr);
+    HIPCHK(h, hipGetLastError());
+    return KDF_OK;
+}
+
+static int upload_stream(kdf_engine *h, const uint64_t *packed, const uint64_t *invalid, uint64_t n_bases,
+                         uint64_t **d_packed, uint64_t **d_invalid) {
+    uint64_t pw, mw;
+    kdf_stream_words(n_bases, &pw, &mw);
+    int rc;
+    if ((rc = stage_reserve(h, 0, pw * 8))) return rc;
+    if ((rc = stage_reserve(h, 1, mw * 8))) return rc;
+    // the caller's arrays hold ceil(n/32) / ceil(n/64) meaningful words; pad on device
+    const uint64_t pw_in = (n_bases + 31) / 32, mw_in = (n_bases + 63) / 64;
+    HIPCHK(h, hipMemsetAsync(h->stage[0], 0, pw * 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->stage[1], 0xFF, mw * 8, h->stream));
+    if (pw_in) HIPCHK(h, hipMemcpyAsync(h->stage[0], packed, pw_in * 8, hipMemcpyHostToDevice, h->stream));
+    if (mw_in) HIPCHK(h, hipMemcpyAsync(h->stage[1], invalid, mw_in * 8, hipMemcpyHostToDevice, h->stream));
+    // bits past n_bases in the last mask word must read "invalid"
+    if (n_bases % 64) {
+        uint64_t last = invalid[mw_in - 1] | (~0ull << (n_bases % 64));
+        HIPCHK(h, hipMemcpyAsync((uint64_t *)h->stage[1] + (mw_in - 1), &last, 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));     // `last` is a stack temporary
+    }
+    *d_packed = (uint64_t *)h->stage[0];
+    *d_invalid = (uint64_t *)h->stage[1];
+    return KDF_OK;
+}
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+
+extern "C" {
+
+const char *kdf_last_error(const kdf_engine *h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+void kdf_stream_words(uint64_t n_bases, uint64_t *packed_words, uint64_t *mask_words) {
+    const uint64_t tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
+    if (packed_words) *packed_words = tiles * 2 + 4;   // a tile reads words [2t, 2t+3]
+    if (mask_words) *mask_words = tiles + 2;           // and mask words [t, t+1]
+}
+
+int kdf_create(int device, int k, uint64_t capacity_hint, kdf_engine **out) {
+    if (!out) return fail(nullptr, KDF_ERR_INVALID, "kdf_create: out is NULL");
+    *out = nullptr;
+    if (k < 1 || k > 63) return fail(nullptr, KDF_ERR_INVALID, "kdf_create: k=%d out of range 1..63", k);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(nullptr, KDF_ERR_HIP, "kdf_create: no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, KDF_ERR_INVALID, "kdf_create: device %d of %d", device, ndev);
+    kdf_engine *h = new kdf_engine();
+    h->device = device; h->k = k; h->kw = k <= 32 ? 1 : 2;
+    auto bail = [&](int rc) { g_err = h->err; kdf_destroy(h); return rc; };
+    if ((e = hipSetDevice(device)) != hipSuccess) { h->err = hipGetErrorString(e); return bail(KDF_ERR_HIP); }
+    if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) { h->err = hipGetErrorString(e); return bail(KDF_ERR_HIP); }
+    h->stream = h->own_stream;
+    if ((e = hipMalloc((void **)&h->ctl, sizeof(KdfCtl))) != hipSuccess) { h->err = hipGetErrorString(e); return bail(KDF_ERR_NOMEM); }
+    if ((e = hipMalloc((void **)&h->d_out4, 32)) != hipSuccess) { h->err = hipGetErrorString(e); return bail(KDF_ERR_NOMEM); }
+    if ((e = hipHostMalloc((void **)&h->h_out4, 32)) != hipSuccess) { h->err = hipGetErrorString(e); return bail(KDF_ERR_NOMEM); }
+    int rc = ctl_reset(h, false);
+    if (rc) return bail(rc);
+    rc = table_alloc(h, cap_log2_for(capacity_hint), h->t);
+    if (rc) return bail(rc);
+    h->cap = 1ull << h->t.log2cap;
+    if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) { h->err = hipGetErrorString(e); return bail(KDF_ERR_HIP); }
+    *out = h;
+    return KDF_OK;
+}
+
+void kdf_destroy(kdf_engine *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    table_free(h->t);
+    for (int i = 0; i < 4; ++i) if (h->stage[i]) (void)hipFree(h->stage[i]);
+    if (h->ctl) (void)hipFree(h->ctl);
+    if (h->d_out4) (void)hipFree(h->d_out4);
+    if (h->h_out4) (void)hipHostFree(h->h_out4);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+int kdf_set_stream(kdf_engine *h, void *hip_stream) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return KDF_OK;
+}
+
+int kdf_synchronize(kdf_engine *h) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return KDF_OK;
+}
+
+int kdf_clear(kdf_engine *h) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemsetAsync(h->t.lo, 0xFF, h->cap * 8, h->stream));
+    if (h->kw == 2) HIPCHK(h, hipMemsetAsync(h->t.hi, 0xFF, h->cap * 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->t.cnt, 0, h->cap * 4, h->stream));
+    int rc = ctl_reset(h, false);
+    if (rc) return rc;
+    h->distinct = 0; h->windows = 0; h->filter_mode = false;
+    return KDF_OK;
+}
+
+int kdf_reserve(kdf_engine *h, uint64_t n_keys) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    HIPCHK(h, hipSetDevice(h->device));
+    const uint32_t want = cap_log2_for(std::max(n_keys, h->distinct));
+    if (want <= h->t.log2cap) return KDF_OK;
+    int rc = ctl_sync(h, nullptr);
+    if (rc) return rc;
+    return table_rehash(h, want);
+}
+
+int kdf_stats(kdf_engine *h, uint64_t *capacity, uint64_t *distinct, uint64_t *windows) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    HIPCHK(h, hipSetDevice(h->device));
+    bool full = false;
+    int rc = ctl_sync(h, &full);
+    if (rc) return rc;
+    if (capacity) *capacity = h->cap;
+    if (distinct) *distinct = h->distinct;
+    if (windows) *windows = h->windows;
+    if (full) return fail(h, KDF_ERR_TABLE_FULL, "a bucket overflowed during an earlier call");
+    return KDF_OK;
+}
+
+int kdf_count_reads_dev(kdf_engine *h, const void *d_packed, const void *d_invalid, uint64_t n_bases) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    if (n_bases && (!d_packed || !d_invalid)) return fail(h, KDF_ERR_INVALID, "kdf_count_reads_dev: NULL stream");
+    HIPCHK(h, hipSetDevice(h->device));
+    return count_insert_dev(h, (const uint64_t *)d_packed, (const uint64_t *)d_invalid, n_bases);
+}
+
+int kdf_count_reads(kdf_engine *h, const uint64_t *packed, const uint64_t *invalid, uint64_t n_bases) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    if (n_bases == 0) return KDF_OK;
+    if (!packed || !invalid) return fail(h, KDF_ERR_INVALID, "kdf_count_reads: NULL stream");
+    HIPCHK(h, hipSetDevice(h->device));
+    uint64_t *dp, *dm;
+    int rc = upload_stream(h, packed, invalid, n_bases, &dp, &dm);
+    if (rc) return rc;
+    return count_insert_dev(h, dp, dm, n_bases);
+}
+
+int kdf_load_filter(kdf_engine *h, const uint64_t *keys_lo, const uint64_t *keys_hi, uint64_t n) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    if (n && (!keys_lo || (h->kw == 2 && !keys_hi))) return fail(h, KDF_ERR_INVALID, "kdf_load_filter: NULL keys");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    // size the table for n keys at load <= 0.5, then start from empty
+    const uint32_t want = cap_log2_for(n);
+    if (want != h->t.log2cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        table_free(h->t);
+        if ((rc = table_alloc(h, want, h->t))) return rc;
+        h->cap = 1ull << want;
+        if ((rc = ctl_reset(h, false))) return rc;
+        h->distinct = 0; h->windows = 0;
+    } else if ((rc = kdf_clear(h))) return rc;
+    h->filter_mode = true;
+    if (n == 0) return KDF_OK;
+    if ((rc = stage_reserve(h, 2, n * 8))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->stage[2], keys_lo, n * 8, hipMemcpyHostToDevice, h->stream));
+    if (h->kw == 2) {
+        if ((rc = stage_reserve(h, 3, n * 8))) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->stage[3], keys_hi, n * 8, hipMemcpyHostToDevice, h->stream));
+    }
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (h->kw == 1)
+        hipLaunchKernelGGL(kdf_insert_keys_kernel<1>, dim3(blocks), dim3(256), 0, h->stream,
+                           (const uint64_t *)h->stage[2], (const uint64_t *)nullptr, (const uint32_t *)nullptr, n, h->t, h->ctl, 0);
+    else
+        hipLaunchKernelGGL(kdf_insert_keys_kernel<2>, dim3(blocks), dim3(256), 0, h->stream,
+                           (const uint64_t *)h->stage[2], (const uint64_t *)h->stage[3], (const uint32_t *)nullptr, n, h->t, h->ctl, 0);
+    HIPCHK(h, hipGetLastError());
+    bool full = false;
+    if ((rc = ctl_sync(h, &full))) return rc;
+    if (full) return fail(h, KDF_ERR_TABLE_FULL, "kdf_load_filter: bucket overflow");
+    return KDF_OK;
+}
+
+int kdf_count_reads_filtered_dev(kdf_engine *h, const void *d_packed, const void *d_invalid, uint64_t n_bases) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    if (n_bases && (!d_packed || !d_invalid)) return fail(h, KDF_ERR_INVALID, "kdf_count_reads_filtered_dev: NULL stream");
+    HIPCHK(h, hipSetDevice(h->device));
+    return count_filtered_dev(h, (const uint64_t *)d_packed, (const uint64_t *)d_invalid, n_bases);
+}
+
+int kdf_count_reads_filtered(kdf_engine *h, const uint64_t *packed, const uint64_t *invalid, uint64_t n_bases) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    if (!h->filter_mode) return fail(h, KDF_ERR_STATE, "kdf_count_reads_filtered: no filter loaded (kdf_load_filter)");
+    if (n_bases == 0) return KDF_OK;
+    if (!packed || !invalid) return fail(h, KDF_ERR_INVALID, "kdf_count_reads_filtered: NULL stream");
+    HIPCHK(h, hipSetDevice(h->device));
+    uint64_t *dp, *dm;
+    int rc = upload_stream(h, packed, invalid, n_bases, &dp, &dm);
+    if (rc) return rc;
+    if ((rc = count_filtered_dev(h, dp, dm, n_bases))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // staging buffers are reused by the next call
+    return KDF_OK;
+}
+
+int kdf_query_dev(kdf_engine *h, const void *d_keys_lo, const void *d_keys_hi, uint64_t n, void *d_counts_out) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    if (n == 0) return KDF_OK;
+    if (!d_keys_lo || !d_counts_out || (h->kw == 2 && !d_keys_hi)) return fail(h, KDF_ERR_INVALID, "kdf_query_dev: NULL pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (h->kw == 1)
+        hipLaunchKernelGGL(kdf_query_kernel<1>, dim3(blocks), dim3(256), 0, h->stream,
+                           (const uint64_t *)d_keys_lo, (const uint64_t *)nullptr, n, h->t, (uint32_t *)d_counts_out);
+    else
+        hipLaunchKernelGGL(kdf_query_kernel<2>, dim3(blocks), dim3(256), 0, h->stream,
+                           (const uint64_t *)d_keys_lo, (const uint64_t *)d_keys_hi, n, h->t, (uint32_t *)d_counts_out);
+    HIPCHK(h, hipGetLastError());
+    return KDF_OK;
+}
+
+int kdf_query(kdf_engine *h, const uint64_t *keys_lo, const uint64_t *keys_hi, uint64_t n, uint32_t *counts_out) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    if (n == 0) return KDF_OK;
+    if (!keys_lo || !counts_out || (h->kw == 2 && !keys_hi)) return fail(h, KDF_ERR_INVALID, "kdf_query: NULL pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = stage_reserve(h, 2, n * 8))) return rc;
+    if ((rc = stage_reserve(h, 0, n * 4))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->stage[2], keys_lo, n * 8, hipMemcpyHostToDevice, h->stream));
+    if (h->kw == 2) {
+        if ((rc = stage_reserve(h, 3, n * 8))) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->stage[3], keys_hi, n * 8, hipMemcpyHostToDevice, h->stream));
+    }
+    if ((rc = kdf_query_dev(h, h->stage[2], h->stage[3], n, h->stage[0]))) return rc;
+    HIPCHK(h, hipMemcpyAsync(counts_out, h->stage[0], n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return KDF_OK;
+}
+
+static int export_pass(kdf_engine *h, uint32_t min_count, bool write, uint64_t *olo, uint64_t *ohi,
+                       uint32_t *ocnt, uint64_t out_cap, uint64_t *n_out) {
+    HIPCHK(h, hipMemsetAsync(&h->ctl->cursor, 0, 8, h->stream));
+    const unsigned blocks = (unsigned)((h->cap + 255) / 256);
+    if (h->kw == 1) {
+        if (write) hipLaunchKernelGGL((kdf_export_kernel<1, true>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap);
+        else hipLaunchKernelGGL((kdf_export_kernel<1, false>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap);
+    } else {
+        if (write) hipLaunchKernelGGL((kdf_export_kernel<2, true>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap);
+        else hipLaunchKernelGGL((kdf_export_kernel<2, false>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap);
+    }
+    HIPCHK(h, hipGetLastError());
+    uint64_t cursor = 0;
+    int rc = ctl_sync(h, nullptr, &cursor);
+    if (rc) return rc;
+    *n_out = cursor;
+    return KDF_OK;
+}
+
+int kdf_count_ge(kdf_engine *h, uint32_t min_count, uint64_t *n_out) {
+    if (!h || !n_out) return fail(h, KDF_ERR_INVALID, "kdf_count_ge: NULL pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    return export_pass(h, min_count, false, nullptr, nullptr, nullptr, 0, n_out);
+}
+
+int kdf_export_ge(kdf_engine *h, uint32_t min_count, uint64_t *keys_lo_out, uint64_t *keys_hi_out,
+                  uint32_t *counts_out, uint64_t cap, uint64_t *n_out) {
+    if (!h || !n_out) return fail(h, KDF_ERR_INVALID, "kdf_export_ge: NULL pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    uint64_t n = 0;
+    int rc = export_pass(h, min_count, false, nullptr, nullptr, nullptr, 0, &n);
+    if (rc) return rc;
+    *n_out = n;
+    if (n == 0) return KDF_OK;
+    if (n > cap) return fail(h, KDF_ERR_INVALID, "kdf_export_ge: %llu entries, room for %llu",
+                             (unsigned long long)n, (unsigned long long)cap);
+    if (!keys_lo_out || (h->kw == 2 && !keys_hi_out)) return fail(h, KDF_ERR_INVALID, "kdf_export_ge: NULL key output");
+    if ((rc = stage_reserve(h, 2, n * 8))) return rc;
+    if ((rc = stage_reserve(h, 0, n * 4))) return rc;
+    if (h->kw == 2 && (rc = stage_reserve(h, 3, n * 8))) return rc;
+    uint64_t n2 = 0;
+    rc = export_pass(h, min_count, true, (uint64_t *)h->stage[2], h->kw == 2 ? (uint64_t *)h->stage[3] : nullptr,
+                     (uint32_t *)h->stage[0], n, &n2);
+    if (rc) return rc;
+    if (n2 != n) return fail(h, KDF_ERR_STATE, "kdf_export_ge: table changed between passes");
+    std::string serr;
+    if (kdf_sort_pairs_device((uint64_t *)h->stage[2], h->kw == 2 ? (uint64_t *)h->stage[3] : nullptr,
+                              (uint32_t *)h->stage[0], n, h->stream, serr))
+        return fail(h, KDF_ERR_HIP, "kdf_export_ge: sort failed: %s", serr.c_str());
+    HIPCHK(h, hipMemcpyAsync(keys_lo_out, h->stage[2], n * 8, hipMemcpyDeviceToHost, h->stream));
+    if (h->kw == 2) HIPCHK(h, hipMemcpyAsync(keys_hi_out, h->stage[3], n * 8, hipMemcpyDeviceToHost, h->stream));
+    else if (keys_hi_out) memset(keys_hi_out, 0, n * 8);
+    if (counts_out) HIPCHK(h, hipMemcpyAsync(counts_out, h->stage[0], n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return KDF_OK;
+}
+
+int kdf_scan_reads_dev(kdf_engine *h, const void *d_packed, const void *d_invalid, uint64_t n_bases, void *d_hit_bits) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    if (n_bases == 0) return KDF_OK;
+    if (!d_packed || !d_invalid || !d_hit_bits) return fail(h, KDF_ERR_INVALID, "kdf_scan_reads_dev: NULL pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
+    launch_stream<MODE_SCAN>(h, (const uint64_t *)d_packed, (const uint64_t *)d_invalid, 0, n_tiles, (uint64_t *)d_hit_bits);
+    HIPCHK(h, hipGetLastError());
+    return KDF_OK;
+}
+
+// host-side canonical key of the window at stream position p (used to count
+// the DISTINCT hit k-mers of the few reads that carry hits)
+static inline void host_window_key(const uint64_t *packed, uint64_t p, int k, uint64_t &klo, uint64_t &khi) {
+    unsigned __int128 e = 0;
+    for (int j = 0; j < k; ++j) {
+        const uint64_t q = p + j;
+        const unsigned __int128 b = (packed[q >> 5] >> ((q & 31) * 2)) & 3;
+        e |= b << (2 * j);
+    }
+    const unsigned __int128 mask = (((unsigned __int128)1) << (2 * k)) - 1;
+    unsigned __int128 rc = ~e & mask, fwd = 0;
+    for (int j = 0; j < k; ++j) fwd |= ((e >> (2 * j)) & 3) << (2 * (k - 1 - j));
+    const unsigned __int128 c = fwd < rc ? fwd : rc;
+    klo = (uint64_t)c; khi = (uint64_t)(c >> 64);
+}
+
+int kdf_scan_reads(kdf_engine *h, const uint64_t *packed, const uint64_t *invalid, uint64_t n_bases,
+                   const int64_t *read_offsets, int64_t n_reads, uint64_t *hit_bits, uint32_t *distinct_out) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    if (!hit_bits) return fail(h, KDF_ERR_INVALID, "kdf_scan_reads: hit_bits is NULL");
+    uint64_t pw, mw;
+    kdf_stream_words(n_bases, &pw, &mw);
+    memset(hit_bits, 0, mw * 8);
+    if (distinct_out && n_reads > 0) memset(distinct_out, 0, (size_t)n_reads * 4);
+    if (n_bases == 0) return KDF_OK;
+    if (!packed || !invalid) return fail(h, KDF_ERR_INVALID, "kdf_scan_reads: NULL stream");
+    HIPCHK(h, hipSetDevice(h->device));
+    uint64_t *dp, *dm;
+    int rc = upload_stream(h, packed, invalid, n_bases, &dp, &dm);
+    if (rc) return rc;
+    if ((rc = stage_reserve(h, 2, mw * 8))) return rc;
+    if ((rc = kdf_scan_reads_dev(h, dp, dm, n_bases, h->stage[2]))) return rc;
+    const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
+    HIPCHK(h, hipMemcpyAsync(hit_bits, h->stage[2], n_tiles * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!read_offsets || !distinct_out) return KDF_OK;
+    // distinct hit k-mers per read: only reads with hits are touched
+    std::vector<std::pair<uint64_t, uint64_t>> keys;
+    for (int64_t r = 0; r < n_reads; ++r) {
+        const uint64_t b = (uint64_t)read_offsets[r], e = (uint64_t)read_offsets[r + 1];
+        keys.clear();
+        for (uint64_t wd = b >> 6; wd <= (e ? (e - 1) >> 6 : 0) && wd < n_tiles; ++wd) {
+            uint64_t bits = hit_bits[wd];
+            while (bits) {
+                const int bit = __builtin_ctzll(bits);
+                bits &= bits - 1;
+                const uint64_t p = (wd << 6) + bit;
+                if (p < b || p >= e) continue;
+                uint64_t lo, hi;
+                host_window_key(packed, p, h->k, lo, hi);
+                keys.emplace_back(hi, lo);
+            }
+        }
+        if (keys.empty()) continue;
+        std::sort(keys.begin(), keys.end());
+        distinct_out[r] = (uint32_t)(std::unique(keys.begin(), keys.end()) - keys.begin());
+    }
+    return KDF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,222 @@
+"""Read streams: the 2-bit-packed base stream + invalid mask the engine consumes,
+and the host feeders that produce them (ASCII reads, BAM, FASTA).
+
+Replaces the ``samtools fasta -F 0xD00 | ...`` half of the reference's pipes
+(core/jellyfish_wrappers.py:159-165, discovery/pipeline.py:106-112,369-375)
+and pysam's read iteration in Module 3 (core/bam_scanner.py:405-414).
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import byref, c_char_p, c_int32, c_int64, c_uint16, c_uint64, c_void_p, POINTER
+from dataclasses import dataclass, field
+from typing import Iterator, List, Optional, Sequence
+
+import numpy as np
+
+from . import _native
+
+# samtools fasta -F 0xD00: SECONDARY | DUPLICATE | SUPPLEMENTARY
+FLAG_OFF_SAMTOOLS_FASTA = 0xD00
+# Module 3 (bam_scanner.py:406-409): SECONDARY | DUPLICATE only
+FLAG_OFF_MODULE3 = 0x500
+
+
+def stream_words(n_bases: int):
+    pw, mw = c_uint64(0), c_uint64(0)
+    _native.load().kdf_stream_words(int(n_bases), byref(pw), byref(mw))
+    return pw.value, mw.value
+
+
+def _vp(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(c_void_p)
+
+
+@dataclass
+class ReadStream:
+    """One batch of reads as a packed stream (layout: include/kdf.h)."""
+    packed: np.ndarray            # uint64, stream_words()[0] words (zero padded)
+    invalid: np.ndarray           # uint64, stream_words()[1] words (tail = all ones)
+    n_bases: int                  # stream positions, separators included
+    offsets: np.ndarray           # int64[n_reads+1]: start of each read in the stream
+    # per-read metadata (BAM feeders only)
+    flags: Optional[np.ndarray] = None
+    ref_ids: Optional[np.ndarray] = None
+    positions: Optional[np.ndarray] = None
+    names: Optional[List[str]] = None
+
+    @property
+    def n_reads(self) -> int:
+        return len(self.offsets) - 1
+
+    def read_lengths(self) -> np.ndarray:
+        """Bases per read (the separator after each read is not counted)."""
+        return np.diff(self.offsets) - 1
+
+    @staticmethod
+    def empty() -> "ReadStream":
+        pw, mw = stream_words(0)
+        return ReadStream(np.zeros(pw, np.uint64), np.full(mw, ~np.uint64(0), np.uint64), 0,
+                          np.zeros(1, np.int64))
+
+    @staticmethod
+    def from_ascii(buf: np.ndarray, offs: np.ndarray) -> "ReadStream":
+        """ASCII records (uint8 buffer + int64 offsets[n+1]) -> stream."""
+        lib = _native.load()
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.int64)
+        n_reads = len(offs) - 1
+        total = int(offs[-1] - offs[0]) + n_reads if n_reads else 0
+        pw, mw = stream_words(total)
+        packed = np.zeros(pw, np.uint64)
+        invalid = np.full(mw, ~np.uint64(0), np.uint64)
+        so = np.zeros(n_reads + 1, np.int64)
+        nb = c_uint64(0)
+        rc = lib.kdf_pack_reads(_vp(buf), _vp(offs), n_reads, _vp(packed), _vp(invalid), _vp(so), byref(nb))
+        _native.check(rc)
+        # words the packer did not touch keep their padding defaults
+        return ReadStream(packed, invalid, nb.value, so)
+
+    @staticmethod
+    def from_strings(reads: Sequence) -> "ReadStream":
+        bs = [r if isinstance(r, (bytes, bytearray)) else r.encode() for r in reads]
+        offs = np.zeros(len(bs) + 1, dtype=np.int64)
+        if bs:
+            offs[1:] = np.cumsum([len(b) for b in bs])
+        buf = np.frombuffer(b"".join(bs), dtype=np.uint8) if bs else np.zeros(0, np.uint8)
+        return ReadStream.from_ascii(buf, offs)
+
+
+class _Reader:
+    """Iterator over ReadStream batches from a native kdf_reader."""
+
+    def __init__(self, handle, max_bases: int, max_reads: int, want_meta: bool):
+        self._h = handle
+        self.max_bases = int(max_bases)
+        self.max_reads = int(max_reads)
+        self.want_meta = want_meta
+        self._lib = _native.load()
+
+    def close(self):
+        if self._h:
+            self._lib.kdf_reader_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __iter__(self) -> Iterator[ReadStream]:
+        lib = self._lib
+        pw, mw = stream_words(self.max_bases)
+        while self._h:
+            packed = np.zeros(pw, np.uint64)
+            invalid = np.full(mw, ~np.uint64(0), np.uint64)
+            so = np.zeros(self.max_reads + 1, np.int64)
+            n_reads, nb = c_int64(0), c_uint64(0)
+            rc = lib.kdf_reader_next(self._h, self.max_bases, self.max_reads, _vp(packed), _vp(invalid),
+                                     _vp(so), byref(n_reads), byref(nb))
+            _native.check_reader(rc, self._h)
+            n = n_reads.value
+            if n == 0:
+                break
+            pw_used, mw_used = stream_words(nb.value)
+            st = ReadStream(packed[:pw_used], invalid[:mw_used], nb.value, so[:n + 1].copy())
+            # the reader only finishes the last mask word; restore padding defaults
+            st.packed[(nb.value + 31) // 32:] = 0
+            st.invalid[(nb.value + 63) // 64:] = ~np.uint64(0)
+            if self.want_meta:
+                f, r, p = POINTER(c_uint16)(), POINTER(c_int32)(), POINTER(c_int32)()
+                nbuf, noff = c_char_p(), POINTER(c_int64)()
+                lib.kdf_reader_last_meta(self._h, byref(f), byref(r), byref(p), byref(nbuf), byref(noff))
+                st.flags = np.ctypeslib.as_array(f, (n,)).copy()
+                st.ref_ids = np.ctypeslib.as_array(r, (n,)).copy()
+                st.positions = np.ctypeslib.as_array(p, (n,)).copy()
+                offs = np.ctypeslib.as_array(noff, (n,))
+                base = ctypes.cast(nbuf, c_void_p).value
+                st.names = [ctypes.string_at(base + int(o)).decode() for o in offs]
+            yield st
+        self.close()
+
+
+def bam_reader(path: str, flag_off: int = FLAG_OFF_SAMTOOLS_FASTA, collapse: bool = True,
+               max_bases: int = 1 << 26, max_reads: int = 1 << 20, threads: int = 1,
+               want_meta: bool = False) -> _Reader:
+    """``samtools fasta -F flag_off`` as an iterator of ReadStream batches."""
+    h = c_void_p()
+    rc = _native.load().kdf_bam_open(path.encode(), flag_off, 1 if collapse else 0, threads, byref(h))
+    _native.check_reader(rc, None)
+    return _Reader(h, max_bases, max_reads, want_meta)
+
+
+def fasta_reader(path: str, k: int, max_bases: int = 1 << 26, max_reads: int = 1 << 16,
+                 want_meta: bool = False) -> _Reader:
+    h = c_void_p()
+    rc = _native.load().kdf_fasta_open(path.encode(), int(k), byref(h))
+    _native.check_reader(rc, None)
+    return _Reader(h, max_bases, max_reads, want_meta)
+
+
+# --------------------------------------------------------------------------
+# k-mer string <-> key codec (Jellyfish encoding, A=0 C=1 G=2 T=3, MSB first)
+# --------------------------------------------------------------------------
+
+_ENC = np.full(256, 255, dtype=np.uint8)
+for _i, _c in enumerate(b"ACGT"):
+    _ENC[_c] = _i
+    _ENC[_c + 32] = _i          # lower case
+_DEC = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def kmers_to_keys(kmers: Sequence[str], k: int, canonical: bool = True):
+    """K-mer strings -> (lo, hi) uint64 arrays of (canonical) keys."""
+    n = len(kmers)
+    lo = np.zeros(n, np.uint64)
+    hi = np.zeros(n, np.uint64)
+    if n == 0:
+        return lo, hi
+    raw = np.frombuffer("".join(kmers).encode(), dtype=np.uint8)
+    if raw.size != n * k:
+        raise ValueError("k-mer of wrong length in input")
+    codes = _ENC[raw].reshape(n, k)
+    if (codes > 3).any():
+        raise ValueError("non-ACGT base in k-mer")
+    codes = codes.astype(np.uint64)
+
+    def pack(c):
+        plo = np.zeros(n, np.uint64)
+        phi = np.zeros(n, np.uint64)
+        for i in range(k):
+            sh = 2 * (k - 1 - i)
+            if sh >= 64:
+                phi |= c[:, i] << np.uint64(sh - 64)
+            else:
+                plo |= c[:, i] << np.uint64(sh)
+        return plo, phi
+
+    flo, fhi = pack(codes)
+    if not canonical:
+        return flo, fhi
+    rlo, rhi = pack((np.uint64(3) - codes)[:, ::-1])
+    fw = (fhi < rhi) | ((fhi == rhi) & (flo <= rlo))
+    return np.where(fw, flo, rlo), np.where(fw, fhi, rhi)
+
+
+def keys_to_kmers(lo: np.ndarray, hi: Optional[np.ndarray], k: int) -> List[str]:
+    n = len(lo)
+    if n == 0:
+        return []
+    lo = np.asarray(lo, np.uint64)
+    hi = np.zeros(n, np.uint64) if hi is None else np.asarray(hi, np.uint64)
+    out = np.empty((n, k), dtype=np.uint8)
+    for i in range(k):
+        sh = 2 * (k - 1 - i)
+        src = (hi >> np.uint64(sh - 64)) if sh >= 64 else (lo >> np.uint64(sh))
+        out[:, i] = _DEC[(src & np.uint64(3)).astype(np.intp)]
+    flat = out.tobytes().decode()
+    return [flat[i * k:(i + 1) * k] for i in range(n)]

@@ -1,0 +1,118 @@
+"""GPU parity (through the C ABI) against the oracle: count, count --if, query,
+dump, scan -- narrow (k<=32) and wide (33<=k<=63) keys, ragged/empty inputs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_reads(rng, n, lo, hi, n_frac=0.01, genome=None):
+    out = []
+    for _ in range(n):
+        L = int(rng.integers(lo, hi + 1))
+        if genome is not None and L <= len(genome):
+            s = int(rng.integers(0, len(genome) - L + 1))
+            a = genome[s:s + L].copy()
+        else:
+            a = rng.integers(0, 4, L).astype(np.uint8)
+        chars = np.frombuffer(b"ACGT", np.uint8)[a].copy()
+        nmask = rng.random(L) < n_frac
+        chars[nmask] = ord("N")
+        s = chars.tobytes().decode()
+        if rng.random() < 0.3:
+            s = s.lower()
+        out.append(s)
+    return out
+
+
+def oracle_sorted(O, k, reads):
+    t = O.OracleTable(k, 1 << 12).count_reads(reads)
+    return t, t.export_ge(0)
+
+
+@pytest.mark.parametrize("k", [5, 15, 31, 32, 33, 47, 63])
+def test_count_export_matches_oracle(oracle, k):
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    rng = np.random.default_rng(100 + k)
+    genome = rng.integers(0, 4, 20000).astype(np.uint8)
+    reads = rand_reads(rng, 400, 0, 300, genome=genome) + ["", "A", "N" * 70, "ACGT" * 40]
+    t, (lo, hi, cnt) = oracle_sorted(oracle, k, reads)
+    with KmerEngine(k, capacity_hint=1024) as e:      # small hint: exercises grow/rehash
+        e.count(ReadStream.from_strings(reads))
+        glo, ghi, gcnt = e.export_ge(0)
+        cap, distinct, windows = e.stats()
+        assert windows == oracle.count_windows(reads, k)
+        assert distinct == len(lo)
+        np.testing.assert_array_equal(glo, lo)
+        np.testing.assert_array_equal(ghi, hi)
+        np.testing.assert_array_equal(gcnt, cnt)
+        # dump -L 2
+        lo2, hi2, c2 = t.export_ge(2)
+        g2 = e.export_ge(2)
+        np.testing.assert_array_equal(g2[0], lo2)
+        np.testing.assert_array_equal(g2[1], hi2)
+        np.testing.assert_array_equal(g2[2], c2)
+        # query: present + absent keys, input order
+        q_lo = np.concatenate([lo[::-1][:100], rng.integers(0, 1 << 62, 50, dtype=np.uint64)])
+        q_hi = np.concatenate([hi[::-1][:100], np.zeros(50, np.uint64)])
+        np.testing.assert_array_equal(e.query(q_lo, q_hi), t.query(q_lo, q_hi))
+
+
+@pytest.mark.parametrize("k", [7, 31, 41, 63])
+def test_count_filtered_and_scan(oracle, k):
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream, hit_positions
+    rng = np.random.default_rng(7 + k)
+    genome = rng.integers(0, 4, 8000).astype(np.uint8)
+    child = rand_reads(rng, 200, 20, 260, genome=genome)
+    parent = rand_reads(rng, 300, 0, 260, genome=genome)
+    _, (lo, hi, cnt) = oracle_sorted(oracle, k, child)
+    sel = rng.random(len(lo)) < 0.5
+    flo, fhi = lo[sel], hi[sel]
+    ot = oracle.OracleTable(k, 1 << 12).load_filter(flo, fhi).count_reads_filtered(parent)
+    with KmerEngine(k) as e:
+        e.load_filter(flo, fhi)
+        st = ReadStream.from_strings(parent)
+        e.count_filtered(st)
+        np.testing.assert_array_equal(e.query(lo, hi), ot.query(lo, hi))
+        glo, ghi, gcnt = e.export_ge(0)      # filter keys never seen report 0
+        olo, ohi, ocnt = ot.export_ge(0)
+        np.testing.assert_array_equal(glo, olo)
+        np.testing.assert_array_equal(gcnt, ocnt)
+        # scan: hit iff stored with count > 0
+        hits, distinct = e.scan(st)
+        ohit, odist = ot.scan_reads(parent)
+        np.testing.assert_array_equal(distinct, odist)
+        buf_off = 0
+        for r, read in enumerate(parent):
+            s, eoff = int(st.offsets[r]), int(st.offsets[r]) + len(read)
+            got = hit_positions(hits, s, eoff)
+            exp = np.nonzero(ohit[buf_off:buf_off + len(read)])[0]
+            np.testing.assert_array_equal(got, exp)
+            buf_off += len(read)
+
+
+def test_empty_inputs(oracle):
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    with KmerEngine(31) as e:
+        e.count(ReadStream.from_strings([]))
+        assert e.stats()[1:] == (0, 0)
+        assert e.count_ge(0) == 0
+        lo, hi, c = e.export_ge(1)
+        assert len(lo) == 0
+        assert len(e.query(np.zeros(0, np.uint64))) == 0
+        e.load_filter(np.zeros(0, np.uint64))
+        e.count_filtered(ReadStream.from_strings(["ACGT" * 20]))
+        assert e.count_ge(0) == 0
+
+
+def test_errors_are_loud():
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    from kmer_denovo_filter_amd._native import KdfError
+    with pytest.raises(ValueError):
+        KmerEngine(64)
+    with KmerEngine(31) as e:
+        with pytest.raises(KdfError):
+            e.count_filtered(ReadStream.from_strings(["ACGT" * 20]))   # no filter loaded
+        e.load_filter(np.array([5], np.uint64))
+        with pytest.raises(KdfError):
+            e.count(ReadStream.from_strings(["ACGT" * 20]))            # filter mode: insert refused
