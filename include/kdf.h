@@ -77,6 +77,13 @@ int kdf_reserve(kdf_engine *h, uint64_t n_keys);
  * by the count calls since the last clear.  Any pointer may be NULL. */
 int kdf_stats(kdf_engine *h, uint64_t *capacity, uint64_t *distinct, uint64_t *windows);
 
+/* Measurement hook (bench.py): when enabled, every launch of the dominant
+ * stream kernel is bracketed by HIP events on the launch stream.
+ * kdf_profile_read returns the summed kernel milliseconds, the number of
+ * launches and the stream positions they covered since kdf_profile(h, 1). */
+int kdf_profile(kdf_engine *h, int enable);
+int kdf_profile_read(kdf_engine *h, double *kernel_ms, uint64_t *launches, uint64_t *positions);
+
 /* ------------------------------------------------- count (insert) stage -- */
 
 /* `jellyfish count -m k -C` over a read stream: every valid window's canonical
@@ -90,6 +97,16 @@ int kdf_count_reads(kdf_engine *h, const uint64_t *packed, const uint64_t *inval
  * kdf_stream_words() says). */
 int kdf_count_reads_dev(kdf_engine *h, const void *d_packed, const void *d_invalid,
                         uint64_t n_bases);
+
+/* Insert-or-add explicit (key, count) pairs: key i gains counts[i] (counts ==
+ * NULL adds 0, i.e. plain insertion).  Loads an on-disk index into the table
+ * (`jellyfish query` mmaps the .jf; discovery/pipeline.py:286-288) and merges
+ * per-GPU partial counts after the owner-partitioned exchange (`jellyfish
+ * merge`, core/jellyfish_wrappers.py:335-366). */
+int kdf_add_pairs(kdf_engine *h, const uint64_t *keys_lo, const uint64_t *keys_hi,
+                  const uint32_t *counts, uint64_t n);
+int kdf_add_pairs_dev(kdf_engine *h, const void *d_keys_lo, const void *d_keys_hi,
+                      const void *d_counts, uint64_t n);
 
 /* ------------------------------------------------ count --if (filter) ---- */
 

@@ -27,8 +27,12 @@ SYMBOLS = [
     ("kdf_clear", c_int, [_P]),
     ("kdf_reserve", c_int, [_P, c_uint64]),
     ("kdf_stats", c_int, [_P, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
+    ("kdf_profile", c_int, [_P, c_int]),
+    ("kdf_profile_read", c_int, [_P, POINTER(ctypes.c_double), POINTER(c_uint64), POINTER(c_uint64)]),
     ("kdf_count_reads", c_int, [_P, _P, _P, c_uint64]),
     ("kdf_count_reads_dev", c_int, [_P, _P, _P, c_uint64]),
+    ("kdf_add_pairs", c_int, [_P, _P, _P, _P, c_uint64]),
+    ("kdf_add_pairs_dev", c_int, [_P, _P, _P, _P, c_uint64]),
     ("kdf_load_filter", c_int, [_P, _P, _P, c_uint64]),
     ("kdf_count_reads_filtered", c_int, [_P, _P, _P, c_uint64]),
     ("kdf_count_reads_filtered_dev", c_int, [_P, _P, _P, c_uint64]),

@@ -138,38 +138,58 @@ __global__ __launch_bounds__(256) void kdf_query_kernel(
     out[i] = (s == ~0ull) ? 0u : t.cnt[s];
 }
 
-// dump -L: count / append entries with cnt >= min_count.  Append positions are
-// reserved per wave (ballot + one atomic), so a wave's entries are contiguous.
+// dump -L: count / append entries with cnt >= min_count.  Each wave owns a
+// chunk of EXPORT_ROWS x 64 consecutive slots: it counts its matches, reserves
+// its output range with ONE atomic, then re-reads the (cache-resident) chunk and
+// writes.  One same-address atomic per 2048 slots instead of one per 64.
+#define KDF_EXPORT_ROWS 32
 template <int KW, bool WRITE>
 __global__ __launch_bounds__(256) void kdf_export_kernel(
     KdfTable t, uint32_t min_count, KdfCtl *ctl, uint64_t *__restrict__ olo,
     uint64_t *__restrict__ ohi, uint32_t *__restrict__ ocnt, uint64_t out_cap)
 {
     const uint64_t cap = 1ull << t.log2cap;
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool keep = false;
-    uint64_t lo = 0, hi = 0; uint32_t c = 0;
-    if (i < cap) {
-        lo = t.lo[i];
-        if (KW == 2) hi = t.hi[i];
-        const bool occ = KW == 1 ? (lo != KDF_EMPTY) : (hi != KDF_EMPTY);
-        c = t.cnt[i];
-        keep = occ && c >= min_count;
-    }
-    const unsigned long long b = __ballot(keep);
-    if (b == 0) return;
     const int lane = threadIdx.x & 63;
-    const int n = __popcll(b);
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(&ctl->cursor, (unsigned long long)n);
-    base = __shfl(base, 0);
-    if (WRITE && keep) {
-        const uint64_t pos = base + __popcll(b & ((1ull << lane) - 1));
-        if (pos < out_cap) {
-            olo[pos] = lo;
-            if (KW == 2 && ohi) ohi[pos] = hi;
-            if (ocnt) ocnt[pos] = c;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t first = wave * (KDF_EXPORT_ROWS * 64);
+    if (first >= cap) return;
+    uint32_t mine = 0;
+#pragma unroll 4
+    for (int r = 0; r < KDF_EXPORT_ROWS; ++r) {
+        const uint64_t i = first + (uint64_t)r * 64 + lane;
+        if (i < cap) {
+            const bool occ = KW == 1 ? (t.lo[i] != KDF_EMPTY) : (t.hi[i] != KDF_EMPTY);
+            mine += (occ && t.cnt[i] >= min_count) ? 1u : 0u;
         }
+    }
+    uint32_t tot = mine;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+    if (tot == 0) return;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&ctl->cursor, (unsigned long long)tot);
+    base = __shfl(base, 0);
+    if (!WRITE) return;
+    for (int r = 0; r < KDF_EXPORT_ROWS; ++r) {
+        const uint64_t i = first + (uint64_t)r * 64 + lane;
+        bool keep = false; uint64_t lo = 0, hi = 0; uint32_t c = 0;
+        if (i < cap) {
+            lo = t.lo[i];
+            if (KW == 2) hi = t.hi[i];
+            const bool occ = KW == 1 ? (lo != KDF_EMPTY) : (hi != KDF_EMPTY);
+            c = t.cnt[i];
+            keep = occ && c >= min_count;
+        }
+        const unsigned long long b = __ballot(keep);
+        if (keep) {
+            const uint64_t pos = base + __popcll(b & ((1ull << lane) - 1));
+            if (pos < out_cap) {
+                olo[pos] = lo;
+                if (KW == 2 && ohi) ohi[pos] = hi;
+                if (ocnt) ocnt[pos] = c;
+            }
+        }
+        base += __popcll(b);
     }
 }
 
@@ -202,6 +222,12 @@ struct kdf_engine {
     // grow-only device staging for the host-buffer entry points
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t stage_bytes[4] = {0, 0, 0, 0};
+    // optional HIP-event timing of the dominant (stream) kernel
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;   // pending start/stop pairs
+    std::vector<uint64_t> prof_tiles;
+    double prof_ms = 0.0;
+    uint64_t prof_launches = 0, prof_positions = 0;
     std::string err;
 };
 
@@ -322,12 +348,35 @@ template <int MODE>
 static void launch_stream(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid,
                           uint64_t tile0, uint64_t n_tiles, uint64_t *d_hits) {
     const unsigned blocks = (unsigned)((n_tiles + 255) / 256);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->prof) {
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, h->stream);
+    }
     if (h->kw == 1)
         hipLaunchKernelGGL((kdf_stream_kernel<1, MODE>), dim3(blocks), dim3(256), 0, h->stream,
                            d_packed, d_invalid, tile0, n_tiles, h->k, h->t, h->ctl, d_hits);
     else
         hipLaunchKernelGGL((kdf_stream_kernel<2, MODE>), dim3(blocks), dim3(256), 0, h->stream,
                            d_packed, d_invalid, tile0, n_tiles, h->k, h->t, h->ctl, d_hits);
+    if (h->prof) {
+        (void)hipEventRecord(e1, h->stream);
+        h->prof_ev.emplace_back(e0, e1);
+        h->prof_tiles.push_back(n_tiles);
+    }
+}
+
+// fold finished event pairs into the running totals (synchronises on them)
+static void prof_collect(kdf_engine *h) {
+    for (size_t i = 0; i < h->prof_ev.size(); ++i) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(h->prof_ev[i].second);
+        if (hipEventElapsedTime(&ms, h->prof_ev[i].first, h->prof_ev[i].second) == hipSuccess) {
+            h->prof_ms += ms; h->prof_launches++; h->prof_positions += h->prof_tiles[i] * KDF_TILE;
+        }
+        (void)hipEventDestroy(h->prof_ev[i].first); (void)hipEventDestroy(h->prof_ev[i].second);
+    }
+    h->prof_ev.clear(); h->prof_tiles.clear();
 }
 
 // insert-mode count over a device-resident stream.  The stream is walked in
@@ -437,6 +486,7 @@ void kdf_destroy(kdf_engine *h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     table_free(h->t);
+    prof_collect(h);
     for (int i = 0; i < 4; ++i) if (h->stage[i]) (void)hipFree(h->stage[i]);
     if (h->ctl) (void)hipFree(h->ctl);
     if (h->d_out4) (void)hipFree(h->d_out4);
@@ -549,6 +599,53 @@ int kdf_load_filter(kdf_engine *h, const uint64_t *keys_lo, const uint64_t *keys
     return KDF_OK;
 }
 
+// insert-or-add (key, count) pairs resident in HBM; grows the table first so the
+// pairs fit at load <= 0.5 even if all of them are new
+static int add_pairs_dev(kdf_engine *h, const uint64_t *d_lo, const uint64_t *d_hi, const uint32_t *d_cnt, uint64_t n) {
+    if (n == 0) return KDF_OK;
+    int rc = ctl_sync(h, nullptr);
+    if (rc) return rc;
+    const uint32_t want = cap_log2_for(h->distinct + n);
+    if (want > h->t.log2cap && (rc = table_rehash(h, want))) return rc;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (h->kw == 1)
+        hipLaunchKernelGGL(kdf_insert_keys_kernel<1>, dim3(blocks), dim3(256), 0, h->stream, d_lo, (const uint64_t *)nullptr, d_cnt, n, h->t, h->ctl, 0);
+    else
+        hipLaunchKernelGGL(kdf_insert_keys_kernel<2>, dim3(blocks), dim3(256), 0, h->stream, d_lo, d_hi, d_cnt, n, h->t, h->ctl, 0);
+    HIPCHK(h, hipGetLastError());
+    bool full = false;
+    if ((rc = ctl_sync(h, &full))) return rc;
+    if (full) return fail(h, KDF_ERR_TABLE_FULL, "kdf_add_pairs: bucket overflow");
+    return KDF_OK;
+}
+
+int kdf_add_pairs_dev(kdf_engine *h, const void *d_keys_lo, const void *d_keys_hi, const void *d_counts, uint64_t n) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    if (n && (!d_keys_lo || (h->kw == 2 && !d_keys_hi))) return fail(h, KDF_ERR_INVALID, "kdf_add_pairs_dev: NULL keys");
+    HIPCHK(h, hipSetDevice(h->device));
+    return add_pairs_dev(h, (const uint64_t *)d_keys_lo, (const uint64_t *)d_keys_hi, (const uint32_t *)d_counts, n);
+}
+
+int kdf_add_pairs(kdf_engine *h, const uint64_t *keys_lo, const uint64_t *keys_hi, const uint32_t *counts, uint64_t n) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    if (n == 0) return KDF_OK;
+    if (!keys_lo || (h->kw == 2 && !keys_hi)) return fail(h, KDF_ERR_INVALID, "kdf_add_pairs: NULL keys");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = stage_reserve(h, 2, n * 8))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->stage[2], keys_lo, n * 8, hipMemcpyHostToDevice, h->stream));
+    if (h->kw == 2) {
+        if ((rc = stage_reserve(h, 3, n * 8))) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->stage[3], keys_hi, n * 8, hipMemcpyHostToDevice, h->stream));
+    }
+    if (counts) {
+        if ((rc = stage_reserve(h, 0, n * 4))) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->stage[0], counts, n * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    return add_pairs_dev(h, (const uint64_t *)h->stage[2], (const uint64_t *)h->stage[3],
+                         counts ? (const uint32_t *)h->stage[0] : nullptr, n);
+}
+
 int kdf_count_reads_filtered_dev(kdf_engine *h, const void *d_packed, const void *d_invalid, uint64_t n_bases) {
     if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
     if (n_bases && (!d_packed || !d_invalid)) return fail(h, KDF_ERR_INVALID, "kdf_count_reads_filtered_dev: NULL stream");
@@ -608,7 +705,8 @@ int kdf_query(kdf_engine *h, const uint64_t *keys_lo, const uint64_t *keys_hi, u
 static int export_pass(kdf_engine *h, uint32_t min_count, bool write, uint64_t *olo, uint64_t *ohi,
                        uint32_t *ocnt, uint64_t out_cap, uint64_t *n_out) {
     HIPCHK(h, hipMemsetAsync(&h->ctl->cursor, 0, 8, h->stream));
-    const unsigned blocks = (unsigned)((h->cap + 255) / 256);
+    const uint64_t waves = (h->cap + KDF_EXPORT_ROWS * 64 - 1) / (KDF_EXPORT_ROWS * 64);
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
     if (h->kw == 1) {
         if (write) hipLaunchKernelGGL((kdf_export_kernel<1, true>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap);
         else hipLaunchKernelGGL((kdf_export_kernel<1, false>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap);
@@ -730,6 +828,23 @@ int kdf_scan_reads(kdf_engine *h, const uint64_t *packed, const uint64_t *invali
         std::sort(keys.begin(), keys.end());
         distinct_out[r] = (uint32_t)(std::unique(keys.begin(), keys.end()) - keys.begin());
     }
+    return KDF_OK;
+}
+
+int kdf_profile(kdf_engine *h, int enable) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    prof_collect(h);
+    h->prof = enable != 0;
+    h->prof_ms = 0.0; h->prof_launches = 0; h->prof_positions = 0;
+    return KDF_OK;
+}
+
+int kdf_profile_read(kdf_engine *h, double *kernel_ms, uint64_t *launches, uint64_t *positions) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    prof_collect(h);
+    if (kernel_ms) *kernel_ms = h->prof_ms;
+    if (launches) *launches = h->prof_launches;
+    if (positions) *positions = h->prof_positions;
     return KDF_OK;
 }
 

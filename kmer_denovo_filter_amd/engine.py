@@ -83,6 +83,16 @@ class KmerEngine:
         self._ck(self._lib.kdf_stats(self._h, byref(c), byref(d), byref(w)))
         return c.value, d.value, w.value
 
+    def profile(self, enable: bool = True):
+        self._ck(self._lib.kdf_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        """(kernel ms, launches, stream positions) of the stream kernel since profile(True)."""
+        import ctypes
+        ms, n, p = ctypes.c_double(0), c_uint64(0), c_uint64(0)
+        self._ck(self._lib.kdf_profile_read(self._h, byref(ms), byref(n), byref(p)))
+        return ms.value, n.value, p.value
+
     # -- count / filter ----------------------------------------------------
     def count(self, stream: ReadStream):
         self._ck(self._lib.kdf_count_reads(self._h, _vp(stream.packed), _vp(stream.invalid), stream.n_bases))
@@ -91,6 +101,19 @@ class KmerEngine:
     def count_dev(self, d_packed: int, d_invalid: int, n_bases: int):
         """Stream resident in HBM (raw device pointers, padded per stream_words)."""
         self._ck(self._lib.kdf_count_reads_dev(self._h, c_void_p(d_packed), c_void_p(d_invalid), int(n_bases)))
+        return self
+
+    def add_pairs(self, lo: np.ndarray, hi: Optional[np.ndarray] = None, counts: Optional[np.ndarray] = None):
+        """Insert-or-add (key, count) pairs (index load / `jellyfish merge`)."""
+        lo = np.ascontiguousarray(lo, dtype=np.uint64)
+        hi = np.ascontiguousarray(hi, dtype=np.uint64) if self.wide else None
+        cnt = None if counts is None else np.ascontiguousarray(counts, dtype=np.uint32)
+        self._ck(self._lib.kdf_add_pairs(self._h, _vp(lo), _vp(hi), _vp(cnt), len(lo)))
+        return self
+
+    def add_pairs_dev(self, d_lo: int, d_hi: Optional[int], d_counts: Optional[int], n: int):
+        self._ck(self._lib.kdf_add_pairs_dev(self._h, c_void_p(d_lo), c_void_p(d_hi) if d_hi else None,
+                                             c_void_p(d_counts) if d_counts else None, int(n)))
         return self
 
     def load_filter(self, lo: np.ndarray, hi: Optional[np.ndarray] = None):

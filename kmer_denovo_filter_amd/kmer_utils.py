@@ -1,0 +1,149 @@
+"""Drop-in mirror of the k-mer part of ``kmer_denovo_filter/kmer_utils.py``
+(reference lines 15-38, 91-245): ``reverse_complement``, ``canonicalize``,
+``_extract_read_kmers`` and ``JellyfishKmerQuery``.
+
+The string helpers are kept for API compatibility (callers use them on single
+k-mers); bulk work goes through the engine.  ``JellyfishKmerQuery`` keeps its
+duck type (``query_batch``, ``scan_read``, ``close``, ``_cache``, ``jf_path``) but
+probes an HBM-resident table instead of spawning ``jellyfish query`` per batch.
+The GPU context is created on first use, never at construction: the reference
+builds these objects inside forked workers (core/bam_scanner.py:250-281).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import jf_io
+from ._native import KdfError
+from .engine import KmerEngine, hit_positions
+from .reads import ReadStream, keys_to_kmers, kmers_to_keys
+
+_COMP = str.maketrans("ACGTacgt", "TGCAtgca")
+
+
+def reverse_complement(seq):
+    """Reverse complement (case preserved), reference :30-32."""
+    return seq.translate(_COMP)[::-1]
+
+
+def canonicalize(kmer):
+    """Lexicographically smaller of a k-mer and its reverse complement, reference :35-38."""
+    rc = kmer.translate(_COMP)[::-1]
+    return kmer if kmer < rc else rc
+
+
+def _extract_read_kmers(seq, kmer_size):
+    """(canon_at_pos, unique_candidates), reference :91-121: upper-cased read,
+    windows holding 'N' skipped, first-seen order."""
+    seq_len = len(seq)
+    if seq_len < kmer_size:
+        return {}, []
+    seq_upper = seq.upper()
+    canon_at_pos = {}
+    candidates = []
+    for i in range(seq_len - kmer_size + 1):
+        kmer = seq_upper[i:i + kmer_size]
+        if "N" in kmer:
+            continue
+        canon = canonicalize(kmer)
+        canon_at_pos[i] = canon
+        candidates.append(canon)
+    return canon_at_pos, list(dict.fromkeys(candidates))
+
+
+class JellyfishKmerQuery:
+    """Membership probe of canonical k-mers against an index file (reference
+    :124-245).  *jf_path* may be a ``kdf/sorted`` index written by this package or
+    a real Jellyfish ``binary/sorted`` file."""
+
+    def __init__(self, jf_path, device: int = 0):
+        self.jf_path = jf_path
+        self._cache: Dict[str, bool] = {}    # canonical_kmer -> present (count > 0)
+        self._device = device
+        self._engine: Optional[KmerEngine] = None
+        self.kmer_size: Optional[int] = None
+
+    # -- engine ------------------------------------------------------------
+    def _ensure_engine(self) -> KmerEngine:
+        if self._engine is None:
+            try:
+                k, lo, hi, cnt = jf_io.read_index(self.jf_path)
+                eng = KmerEngine(k, capacity_hint=max(len(lo), 1), device=self._device)
+                eng.add_pairs(lo, hi, cnt)
+            except (KdfError, ValueError, OSError) as e:
+                raise RuntimeError(f"jellyfish query failed: {e}") from e
+            self._engine, self.kmer_size = eng, k
+        return self._engine
+
+    def _subprocess_query(self, kmers):
+        """Present (count > 0) subset of *kmers*; name kept from the reference
+        (:152-183) although no subprocess is involved."""
+        kmers = list(kmers)
+        if not kmers:
+            return set()
+        eng = self._ensure_engine()
+        ok = [km for km in kmers if len(km) == eng.k and set(km.upper()) <= set("ACGT")]
+        if not ok:
+            return set()
+        lo, hi = kmers_to_keys(ok, eng.k, canonical=True)
+        try:
+            counts = eng.query(lo, hi)
+        except KdfError as e:
+            raise RuntimeError(f"jellyfish query failed: {e}") from e
+        # jellyfish prints the canonical k-mer; callers pass canonical k-mers
+        return {canonicalize(km.upper()) for km, c in zip(ok, counts) if c != 0}
+
+    def query_batch(self, canonical_kmers):
+        """Set of the given canonical k-mers that are present, with a result
+        cache (reference :185-207)."""
+        if not canonical_kmers:
+            return set()
+        uncached = [k for k in canonical_kmers if k not in self._cache]
+        if uncached:
+            hits = self._subprocess_query(uncached)
+            for k in uncached:
+                self._cache[k] = k in hits
+        return {k for k in canonical_kmers if self._cache.get(k, False)}
+
+    def scan_read(self, seq, kmer_size):
+        """(unique_in_read, kmer_hit_indices) for one read (reference :209-238):
+        one scan-kernel launch over the read instead of a subprocess."""
+        if len(seq) < kmer_size:
+            return set(), set()
+        eng = self._ensure_engine()
+        if kmer_size != eng.k:
+            raise RuntimeError(f"jellyfish query failed: index has k={eng.k}, asked for k={kmer_size}")
+        st = ReadStream.from_strings([seq])
+        try:
+            hits, _ = eng.scan(st, want_distinct=False)
+        except KdfError as e:
+            raise RuntimeError(f"jellyfish query failed: {e}") from e
+        pos = hit_positions(hits, 0, len(seq))
+        if len(pos) == 0:
+            return set(), set()
+        up = seq.upper()
+        unique_in_read = set()
+        for p in pos.tolist():
+            c = canonicalize(up[p:p + kmer_size])
+            unique_in_read.add(c)
+            self._cache[c] = True
+        return unique_in_read, set(pos.tolist())
+
+    def close(self):
+        """Clear the result cache (reference :240-242); the table stays resident."""
+        self._cache.clear()
+
+    def release(self):
+        """Free the HBM table (no reference equivalent: jellyfish's mmap dies with its process)."""
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+
+    def __del__(self):
+        try:
+            self.close()
+            self.release()
+        except Exception:  # noqa: BLE001
+            pass

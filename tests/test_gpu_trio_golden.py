@@ -1,0 +1,137 @@
+"""GPU path (through the C ABI and the drop-in mirrors) against the reference's
+committed goldens on the GIAB mini trio:
+reference index == real Jellyfish file, 51125 -> 6679 -> 630, 195 / 11."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GIAB, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_index_equals_real_jellyfish(oracle, tmp_path):
+    """_ensure_ref_jf builds mini_ref.fa's index; its (key, count) set must be
+    bit-equal to the real Jellyfish binary/sorted fixture."""
+    import shutil
+    from kmer_denovo_filter_amd import jf_io
+    from kmer_denovo_filter_amd.core.jellyfish_wrappers import _ensure_ref_jf
+    fa = str(tmp_path / "mini_ref.fa")
+    shutil.copy(os.path.join(GIAB, "mini_ref.fa"), fa)
+    path = _ensure_ref_jf(fa, 31, 4)
+    assert path == fa + ".k31.jf" and os.path.isfile(path)
+    k, lo, hi, cnt = jf_io.read_index(path)
+    jk, jlo, jhi, jcnt = jf_io.read_index(os.path.join(GIAB, "mini_ref.fa.k31.jf"))
+    assert k == jk == 31 and len(lo) == 45275
+    order = np.argsort(jlo)
+    np.testing.assert_array_equal(lo, jlo[order])
+    np.testing.assert_array_equal(cnt, jcnt[order])
+    assert int(cnt.sum()) == 45804 and int(cnt.max()) == 12
+    # an existing file is returned untouched
+    before = os.path.getmtime(path)
+    assert _ensure_ref_jf(fa, 31, 4) == path and os.path.getmtime(path) == before
+
+
+@pytest.fixture(scope="module")
+def discovery(tmp_path_factory):
+    from kmer_denovo_filter_amd.discovery.pipeline import (
+        _extract_child_kmers_discovery, _filter_parents_discovery, _subtract_reference_kmers)
+    from kmer_denovo_filter_amd.kmer_fasta import read_kmer_fasta_keys
+    tmp = str(tmp_path_factory.mktemp("disc"))
+    out = {}
+    fa, n = _extract_child_kmers_discovery(os.path.join(GIAB, "HG002_child.bam"), None, 31, 3, 4, tmp)
+    out["candidates"] = (n, read_kmer_fasta_keys(fa, 31))
+    # the user-supplied real Jellyfish index (--ref-jf), as in tests/conftest.py:99-111
+    fa2, n2 = _subtract_reference_kmers(os.path.join(GIAB, "mini_ref.fa.k31.jf"), fa, tmp)
+    assert not os.path.exists(fa)                      # input FASTA is deleted
+    out["non_ref"] = (n2, read_kmer_fasta_keys(fa2, 31))
+    n3, fa3 = _filter_parents_discovery(os.path.join(GIAB, "HG004_mother.bam"),
+                                        os.path.join(GIAB, "HG003_father.bam"), None, fa2, 31, 4, tmp, 0)
+    out["proband_unique"] = (n3, read_kmer_fasta_keys(fa3, 31))
+    out["proband_fa"] = fa3
+    out["tmp"] = tmp
+    return out
+
+
+def test_discovery_chain_goldens(oracle, trio_reads, discovery):
+    m = json.load(open(os.path.join(GOLDEN, "example_output_discovery", "giab_discovery.metrics.json")))
+    assert discovery["candidates"][0] == m["child_candidate_kmers"] == 51125
+    assert discovery["non_ref"][0] == m["non_ref_kmers"] == 6679
+    assert discovery["proband_unique"][0] == m["proband_unique_kmers"] == 630
+    # and the surviving SETS are bit-exact against the oracle chain
+    ref = oracle.read_fasta(os.path.join(GIAB, "mini_ref.fa"))
+    rt = oracle.OracleTable(31).count_reads([s for _, s in ref])
+    st = oracle.discovery_chain(trio_reads["child"], trio_reads["mother"], trio_reads["father"], rt, 31, 3, 0)
+    for stage in ("candidates", "non_ref", "proband_unique"):
+        got = np.sort(discovery[stage][1][0])
+        np.testing.assert_array_equal(got, st[stage][0])
+
+
+def test_intermediate_fasta_contract(discovery):
+    lines = open(discovery["proband_fa"]).read().split("\n")
+    assert lines[0] == ">0" and lines[2] == ">1" and len(lines[1]) == 31
+    assert lines[-1] == "" and len(lines) == 2 * 630 + 1
+    assert lines[2 * 629] == ">629"
+
+
+def test_module3_goldens(oracle, discovery):
+    from kmer_denovo_filter_amd.core import bam_scanner
+    from kmer_denovo_filter_amd.core.jellyfish_wrappers import _build_proband_jf_index
+    m = json.load(open(os.path.join(GOLDEN, "example_output_discovery", "giab_discovery.metrics.json")))
+    jf = _build_proband_jf_index(discovery["proband_fa"], 31, discovery["tmp"], 630)
+    assert jf.endswith("proband_unique.jf")
+    bam_scanner._init_scan_worker(jf, 31, m["filters"]["min_distinct_kmers_per_read"])
+    total, unmapped, scanned, kept = bam_scanner.count_informative_reads(os.path.join(GIAB, "HG002_child.bam"))
+    assert total == m["informative_reads"] == 195
+    assert unmapped == m["unmapped_informative_reads"] == 11
+    # per-read hit positions equal the oracle's
+    lo, hi = discovery["proband_unique"][1]
+    _, _, ohits = oracle.module3_scan(os.path.join(GIAB, "HG002_child.bam"), lo, hi, 31, 7)
+    assert len(ohits) == len(kept)
+    okey = {(r.qname, r.flag, r.pos): (pos, d) for r, pos, d in ohits}
+    for inf in kept:
+        pos, d = okey[(inf.query_name, inf.flag, inf.pos)]
+        np.testing.assert_array_equal(inf.kmer_hit_indices, pos)
+        assert inf.n_distinct == d
+
+
+def test_scan_parent_jellyfish_counts(oracle, trio_reads, discovery, tmp_path):
+    """VCF-mode Step 3 wrapper: dict of k-mer -> count (only count >= 1)."""
+    from kmer_denovo_filter_amd.core.jellyfish_wrappers import _scan_parent_jellyfish
+    from kmer_denovo_filter_amd.kmer_fasta import write_kmer_fasta
+    lo, hi = discovery["non_ref"][1]
+    fa = str(tmp_path / "child_kmers.fa")
+    write_kmer_fasta(fa, lo, hi, 31)
+    got = _scan_parent_jellyfish(os.path.join(GIAB, "HG004_mother.bam"), None, fa, 31, str(tmp_path / "mother"), 4,
+                                 n_filter_kmers=len(lo))
+    ot = oracle.OracleTable(31).load_filter(lo, hi).count_reads_filtered(trio_reads["mother"])
+    elo, ehi, ecnt = ot.export_ge(1)
+    exp = {oracle.int_to_kmer(int(l), 31): int(c) for l, c in zip(elo, ecnt)}
+    assert got == exp and len(got) == 6679 - 1513
+
+
+def test_jellyfish_kmer_query_mirror(oracle, discovery):
+    """reference tests/test_kmer_utils.py:594-709 on the engine-backed class."""
+    from kmer_denovo_filter_amd import jf_io
+    from kmer_denovo_filter_amd.core.jellyfish_wrappers import _build_proband_jf_index
+    from kmer_denovo_filter_amd.kmer_utils import JellyfishKmerQuery, _extract_read_kmers, canonicalize
+    import tempfile
+    d = tempfile.mkdtemp()
+    fa = os.path.join(d, "test.fa")
+    open(fa, "w").write(">seq\nACGTACGTACGTACGTACGT\n")
+    jf = _build_proband_jf_index(fa, 5, d)
+    q = JellyfishKmerQuery(jf)
+    assert len(q.query_batch([canonicalize("ACGTA")])) > 0
+    assert len(q.query_batch([canonicalize("TTTTT")])) == 0
+    assert canonicalize("ACGTA") in q._cache
+    hits = q.query_batch([canonicalize("ACGTA"), canonicalize("TTTTT")])
+    assert canonicalize("ACGTA") in hits and canonicalize("TTTTT") not in hits
+    unique, idx = q.scan_read("ACGTACGTACGTACGTACGT", 5)
+    cap, cands = _extract_read_kmers("ACGTACGTACGTACGTACGT", 5)
+    assert unique == set(cands) and idx == set(cap)
+    assert q.scan_read("TTTTTTTTTTTTTTT", 5) == (set(), set())
+    assert q.query_batch([]) == set()
+    q.close()
+    assert len(q._cache) == 0
