@@ -77,6 +77,14 @@ int kdf_reserve(kdf_engine *h, uint64_t n_keys);
  * by the count calls since the last clear.  Any pointer may be NULL. */
 int kdf_stats(kdf_engine *h, uint64_t *capacity, uint64_t *distinct, uint64_t *windows);
 
+/* Tuning knobs and counters (tests force either kernel path through these):
+ *   options  "force_path" 0 auto / 1 direct global-table kernels / 2 binned
+ *            LDS-bucket pipeline; "binned_min_positions" (stream positions from
+ *            which count calls take the binned path); "binned_filtered_min_log2cap"
+ *   stats    "binned_passes", "replayed_buckets", "log2cap", "bucket_bits" */
+int kdf_set_option(kdf_engine *h, const char *name, int64_t value);
+int kdf_get_stat(kdf_engine *h, const char *name, int64_t *value);
+
 /* Measurement hook (bench.py): when enabled, every launch of the dominant
  * stream kernel is bracketed by HIP events on the launch stream.
  * kdf_profile_read returns the summed kernel milliseconds, the number of

@@ -27,6 +27,8 @@ SYMBOLS = [
     ("kdf_clear", c_int, [_P]),
     ("kdf_reserve", c_int, [_P, c_uint64]),
     ("kdf_stats", c_int, [_P, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
+    ("kdf_set_option", c_int, [_P, c_char_p, c_int64]),
+    ("kdf_get_stat", c_int, [_P, c_char_p, POINTER(c_int64)]),
     ("kdf_profile", c_int, [_P, c_int]),
     ("kdf_profile_read", c_int, [_P, POINTER(ctypes.c_double), POINTER(c_uint64), POINTER(c_uint64)]),
     ("kdf_count_reads", c_int, [_P, _P, _P, c_uint64]),

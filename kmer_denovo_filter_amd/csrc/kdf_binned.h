@@ -1,0 +1,457 @@
+// kdf_binned.h -- the LDS-staged-bucket count pipeline ("binned" path).
+//
+// The table (kdf_device.h) is an array of buckets of 2^bucket_bits slots; a
+// key's bucket is the top bits of its hash.  Random probes into an HBM table
+// move a 64-128 B sector per 8 useful bytes and pay a device atomic per window.
+// Instead, a batch of reads is processed as
+//
+//   A0  histogram of the coarse bin (top c1 hash bits) of every valid window
+//   A1  extract canonical k-mers again and scatter them to their coarse bin:
+//       LDS counting sort per slab -> coalesced run writes
+//   B   every CHUNK-entry chunk of a coarse bin is sorted IN PLACE by the next
+//       c2 hash bits; a per-chunk offset table locates each fine run
+//       (no global fine histogram, immune to multiplicity skew)
+//   C   one workgroup per table bucket: bucket slice (keys+counts) lives in
+//       LDS, the bucket's runs are gathered from all chunks of its coarse bin
+//       and inserted / probed with LDS atomics, the slice is written back once.
+//       Transactional per bucket: a bucket that overflows is left untouched in
+//       HBM and flagged; the host grows the table and replays those buckets
+//       through the global-atomic path (D).
+//
+// All of it is placement independent: no workgroup reads another workgroup's
+// output inside a launch.
+#pragma once
+#include "kdf_device.h"
+
+#define KB_THREADS   1024
+#define KB_F_BITS    8                   // fine bins per coarse bin (level-2 radix)
+#define KB_F         (1 << KB_F_BITS)
+#define KB_C1_MAX    9                   // coarse bins <= 512
+#define KB_C_THREADS 512                 // bucket kernel
+
+template <int KW> struct KbCfg;
+template <> struct KbCfg<1> { static constexpr int WPT = 16, CHUNK = 16384; };   // 8-byte entries: 128 KB of LDS
+template <> struct KbCfg<2> { static constexpr int WPT = 8,  CHUNK = 8192;  };   // 16-byte entries
+
+struct KbPlan {
+    uint32_t c1;            // coarse bits
+    uint32_t c2;            // fine bits (<= KB_F_BITS)
+    uint32_t sub_bits;      // table buckets per partition bucket = 2^sub_bits
+    uint32_t log2cap, bucket_bits;
+};
+
+// device scratch shared by the kernels of one pass
+struct KbScratch {
+    unsigned long long *hist1;      // [2^c1]
+    unsigned long long *bin_start;  // [2^c1 + 1]
+    unsigned long long *cursor;     // [2^c1]
+    unsigned long long *chunk_first;// [2^c1 + 1]
+    unsigned long long *totals;     // [4]: n_entries, n_chunks, n_failed, claimed
+    uint32_t *chunk_off;            // [n_chunks][2^c2 + 1]
+    uint32_t *failed;               // bitmap over TABLE buckets (2^(c1+c2+sub_bits) bits)
+    uint64_t *ent_lo;               // entries (keys); wide: lo words
+    uint64_t *ent_hi;               // wide: hi words
+};
+
+__device__ __forceinline__ uint32_t kb_coarse(const KbPlan &p, uint64_t h) {
+    return p.c1 ? (uint32_t)(h >> (64 - p.c1)) : 0u;
+}
+__device__ __forceinline__ uint32_t kb_fine(const KbPlan &p, uint64_t h) {
+    return p.c2 ? (uint32_t)((h >> (64 - p.c1 - p.c2)) & ((1u << p.c2) - 1)) : 0u;
+}
+
+// block-wide exclusive scan of n <= KB_THREADS uint32 values held one per
+// thread (threads >= n pass 0); returns the exclusive prefix, total via *tot.
+__device__ __forceinline__ uint32_t kb_block_exscan(uint32_t v, uint32_t *wsum /* >= 16 words LDS */, uint32_t *tot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t s = lane < nw ? wsum[lane] : 0, si = s;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { uint32_t t = __shfl_up(si, o); if (lane >= o) si += t; }
+        if (lane < nw) wsum[lane] = si - s;
+        if (lane == nw - 1) wsum[16] = si;
+    }
+    __syncthreads();
+    const uint32_t r = wsum[wave] + inc - v;
+    if (tot) *tot = wsum[16];
+    __syncthreads();
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// A: thread -> (tile, part).  A tile = 64 window starts; it is split over
+// 64/WPT threads so a 1024-thread workgroup covers a slab of 1024*WPT positions.
+template <int KW>
+struct KbWindows {
+    static constexpr int WPT = KbCfg<KW>::WPT;
+    static constexpr int NW = KW == 1 ? 3 : 4;
+    uint64_t w[NW];
+    uint32_t valid;       // WPT bits
+    int p0;               // first local position of this thread inside the tile
+    uint64_t kmask;
+    int k;
+    __device__ __forceinline__ void load(const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid,
+                                         uint64_t tile, uint64_t n_tiles, int part, int k_) {
+        k = k_; p0 = part * WPT; valid = 0;
+        kmask = (k >= 32) ? ~0ull : ((1ull << (2 * k)) - 1);
+        if (tile < n_tiles) {
+            const uint64_t v = kdf_valid_windows(invalid[tile], invalid[tile + 1], k);
+            valid = (uint32_t)((v >> p0) & ((1ull << WPT) - 1));
+            if (valid) {
+#pragma unroll
+                for (int i = 0; i < NW; ++i) w[i] = packed[tile * 2 + i];
+            }
+        }
+    }
+    __device__ __forceinline__ void key(int u, uint64_t &lo, uint64_t &hi) const {
+        if constexpr (KW == 1) { lo = kdf_window_narrow(w, p0 + u, k, kmask); hi = 0; }
+        else kdf_window_wide(w, p0 + u, k, lo, hi);
+    }
+};
+
+template <int KW>
+__global__ __launch_bounds__(KB_THREADS) void kb_hist1_kernel(
+    const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid, uint64_t n_tiles, int k,
+    KbPlan plan, KbScratch s)
+{
+    __shared__ uint32_t hist[1 << KB_C1_MAX];
+    constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT;      // threads per tile
+    for (int i = threadIdx.x; i < (1 << plan.c1); i += KB_THREADS) hist[i] = 0;
+    __syncthreads();
+    const uint64_t tile = (uint64_t)blockIdx.x * (KB_THREADS / TPT) + threadIdx.x / TPT;
+    KbWindows<KW> win;
+    win.load(packed, invalid, tile, n_tiles, threadIdx.x % TPT, k);
+    if (win.valid) {
+#pragma unroll
+        for (int u = 0; u < WPT; ++u) {
+            if (!((win.valid >> u) & 1)) continue;
+            uint64_t lo, hi; win.key(u, lo, hi);
+            atomicAdd(&hist[kb_coarse(plan, kdf_hash(lo, hi))], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (1 << plan.c1); i += KB_THREADS)
+        if (hist[i]) atomicAdd(&s.hist1[i], (unsigned long long)hist[i]);
+}
+
+// single workgroup: bin starts, cursors, chunk layout
+__global__ __launch_bounds__(KB_THREADS) void kb_scan1_kernel(KbPlan plan, KbScratch s, uint32_t chunk, KdfCtl *ctl) {
+    __shared__ unsigned long long a[(1 << KB_C1_MAX) + 1], c[(1 << KB_C1_MAX) + 1];
+    const int nb = 1 << plan.c1;
+    if (threadIdx.x == 0) {
+        unsigned long long acc = 0, cacc = 0;
+        for (int i = 0; i < nb; ++i) {
+            a[i] = acc; c[i] = cacc;
+            const unsigned long long n = s.hist1[i];
+            acc += n; cacc += (n + chunk - 1) / chunk;
+        }
+        a[nb] = acc; c[nb] = cacc;
+        s.totals[0] = acc; s.totals[1] = cacc; s.totals[2] = 0; s.totals[3] = 0;
+        if (acc) atomicAdd(&ctl->windows[0], acc);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= nb; i += KB_THREADS) {
+        s.bin_start[i] = a[i]; s.chunk_first[i] = c[i];
+        if (i < nb) s.cursor[i] = a[i];
+    }
+}
+
+template <int KW>
+__global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
+    const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid, uint64_t n_tiles, int k,
+    KbPlan plan, KbScratch s)
+{
+    constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT, SLAB = KB_THREADS * WPT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t *slo = (uint64_t *)smem;                                   // [SLAB]
+    uint64_t *shi = KW == 2 ? slo + SLAB : nullptr;                     // [SLAB] wide
+    uint32_t *hist = (uint32_t *)(smem + (size_t)SLAB * 8 * KW);        // [512]
+    uint32_t *offs = hist + (1 << KB_C1_MAX);                           // [512]
+    uint32_t *wsum = offs + (1 << KB_C1_MAX);                           // [32]
+    unsigned long long *gbase = (unsigned long long *)(wsum + 32);      // [512]
+    const int nb = 1 << plan.c1;
+    for (int i = threadIdx.x; i < nb; i += KB_THREADS) hist[i] = 0;
+    __syncthreads();
+    const uint64_t tile = (uint64_t)blockIdx.x * (KB_THREADS / TPT) + threadIdx.x / TPT;
+    KbWindows<KW> win;
+    win.load(packed, invalid, tile, n_tiles, threadIdx.x % TPT, k);
+    uint64_t klo[WPT], khi[KW == 2 ? WPT : 1];
+    uint32_t br[WPT];                       // bin << 16 | rank  (rank < SLAB <= 16384)
+    if (win.valid) {
+#pragma unroll
+        for (int u = 0; u < WPT; ++u) {
+            if (!((win.valid >> u) & 1)) continue;
+            uint64_t lo, hi; win.key(u, lo, hi);
+            klo[u] = lo; if constexpr (KW == 2) khi[u] = hi;
+            const uint32_t bin = kb_coarse(plan, kdf_hash(lo, hi));
+            br[u] = (bin << 16) | atomicAdd(&hist[bin], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t total = 0;
+    {
+        const uint32_t v = threadIdx.x < nb ? hist[threadIdx.x] : 0;
+        const uint32_t ex = kb_block_exscan(v, wsum, &total);
+        if (threadIdx.x < nb) {
+            offs[threadIdx.x] = ex;
+            gbase[threadIdx.x] = v ? atomicAdd(&s.cursor[threadIdx.x], (unsigned long long)v) : 0ull;
+        }
+    }
+    __syncthreads();
+    if (win.valid) {
+#pragma unroll
+        for (int u = 0; u < WPT; ++u) {
+            if (!((win.valid >> u) & 1)) continue;
+            const uint32_t pos = offs[br[u] >> 16] + (br[u] & 0xFFFF);
+            slo[pos] = klo[u];
+            if constexpr (KW == 2) shi[pos] = khi[u];
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < total; i += KB_THREADS) {
+        const uint64_t lo = slo[i], hi = KW == 2 ? shi[i] : 0;
+        const uint32_t bin = kb_coarse(plan, kdf_hash(lo, hi));
+        const unsigned long long dst = gbase[bin] + (i - offs[bin]);
+        s.ent_lo[dst] = lo;
+        if constexpr (KW == 2) s.ent_hi[dst] = hi;
+    }
+}
+
+// B: one workgroup per chunk; in-place sort by fine bin + offset table
+template <int KW>
+__global__ __launch_bounds__(KB_THREADS) void kb_finesort_kernel(KbPlan plan, KbScratch s)
+{
+    constexpr int CHUNK = KbCfg<KW>::CHUNK, EPT = CHUNK / KB_THREADS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t *slo = (uint64_t *)smem;
+    uint64_t *shi = KW == 2 ? slo + CHUNK : nullptr;
+    uint32_t *hist = (uint32_t *)(smem + (size_t)CHUNK * 8 * KW);       // [256]
+    uint32_t *offs = hist + KB_F;                                        // [256]
+    uint32_t *wsum = offs + KB_F;                                        // [32]
+    unsigned long long &sh_start = *(unsigned long long *)(wsum + 32);
+    uint32_t &sh_len = *(uint32_t *)(wsum + 34);
+    const uint64_t chunk = blockIdx.x;
+    if (threadIdx.x == 0) {
+        // locate the coarse bin of this chunk: chunk_first is ascending
+        const int nb = 1 << plan.c1;
+        int lo = 0, hi = nb;            // largest c with chunk_first[c] <= chunk
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (s.chunk_first[mid] <= chunk) lo = mid; else hi = mid; }
+        const unsigned long long st = s.bin_start[lo] + (chunk - s.chunk_first[lo]) * (unsigned long long)CHUNK;
+        const unsigned long long en = s.bin_start[lo + 1];
+        sh_start = st;
+        sh_len = (uint32_t)((en - st) < (unsigned long long)CHUNK ? (en - st) : (unsigned long long)CHUNK);
+    }
+    const int nf = 1 << plan.c2;
+    for (int i = threadIdx.x; i < KB_F; i += KB_THREADS) hist[i] = 0;
+    __syncthreads();
+    const unsigned long long start = sh_start;
+    const uint32_t len = sh_len;
+    uint64_t klo[EPT], khi[KW == 2 ? EPT : 1];
+    uint32_t br[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const uint32_t i = e * KB_THREADS + threadIdx.x;
+        if (i < len) {
+            klo[e] = s.ent_lo[start + i];
+            if constexpr (KW == 2) khi[e] = s.ent_hi[start + i];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const uint32_t i = e * KB_THREADS + threadIdx.x;
+        if (i < len) {
+            const uint32_t f = kb_fine(plan, kdf_hash(klo[e], KW == 2 ? khi[e] : 0));
+            br[e] = (f << 16) | atomicAdd(&hist[f], 1u);
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t v = threadIdx.x < nf ? hist[threadIdx.x] : 0;
+        const uint32_t ex = kb_block_exscan(v, wsum, nullptr);
+        if (threadIdx.x < nf) {
+            offs[threadIdx.x] = ex;
+            s.chunk_off[chunk * (KB_F + 1) + threadIdx.x] = ex;
+        }
+        if (threadIdx.x == 0) s.chunk_off[chunk * (KB_F + 1) + nf] = len;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const uint32_t i = e * KB_THREADS + threadIdx.x;
+        if (i < len) {
+            const uint32_t pos = offs[br[e] >> 16] + (br[e] & 0xFFFF);
+            slo[pos] = klo[e];
+            if constexpr (KW == 2) shi[pos] = khi[e];
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < len; i += KB_THREADS) {
+        s.ent_lo[start + i] = slo[i];
+        if constexpr (KW == 2) s.ent_hi[start + i] = shi[i];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// C: one workgroup per TABLE bucket.
+enum { KB_MODE_INSERT = 0, KB_MODE_FILTERED = 1, KB_MODE_REPLAY = 2 };
+
+__device__ __forceinline__ void kb_lds_sat_add(uint32_t *p, uint32_t add) {
+    uint32_t old = atomicAdd(p, add);
+    if (old + add < old || old + add == 0xFFFFFFFFu) atomicMax(p, 0xFFFFFFFFu);
+}
+
+// MODE_INSERT / MODE_FILTERED: bucket slice staged in LDS.
+// MODE_REPLAY: only buckets flagged in s.failed, inserted through the global
+// atomic path into table t (which the host has grown since the failed pass;
+// `old_plan` is the plan the partition was built with).
+template <int KW, int MODE>
+__global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
+    KbPlan plan, KbScratch s, KdfTable t, KdfCtl *ctl, int table_nonempty)
+{
+    constexpr int CHUNK = KbCfg<KW>::CHUNK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t B = 1u << plan.bucket_bits;
+    uint64_t *tlo = (uint64_t *)smem;                         // [B]
+    uint64_t *thi = KW == 2 ? tlo + B : nullptr;              // [B] wide
+    uint32_t *tcnt = (uint32_t *)(smem + (size_t)B * 8 * KW); // [B]
+    uint32_t &sh_failed = tcnt[B], &sh_claimed = tcnt[B + 1];
+
+    // `plan` describes the table the partition was built for.  In MODE_REPLAY
+    // that is the OLD geometry (the host has grown the table since) and `t` is
+    // the new table.
+    const uint64_t bucket = blockIdx.x;                       // table bucket of `plan`
+    const uint64_t pb = bucket >> plan.sub_bits;              // partition bucket holding its entries
+    const uint32_t c = (uint32_t)(pb >> plan.c2), f = (uint32_t)(pb & ((1u << plan.c2) - 1));
+    if constexpr (MODE == KB_MODE_REPLAY) {
+        if (!((s.failed[bucket >> 5] >> (bucket & 31)) & 1)) return;
+    }
+    const uint64_t slot0 = bucket << plan.bucket_bits;        // first slot of the bucket in HBM
+    if (threadIdx.x == 0) { sh_failed = 0; sh_claimed = 0; }
+    if constexpr (MODE != KB_MODE_REPLAY) {
+        if (table_nonempty) {
+            for (uint32_t i = threadIdx.x; i < B; i += KB_C_THREADS) {
+                tlo[i] = t.lo[slot0 + i];
+                if constexpr (KW == 2) thi[i] = t.hi[slot0 + i];
+                tcnt[i] = t.cnt[slot0 + i];
+            }
+        } else {
+            for (uint32_t i = threadIdx.x; i < B; i += KB_C_THREADS) {
+                tlo[i] = KDF_EMPTY;
+                if constexpr (KW == 2) thi[i] = KDF_EMPTY;
+                tcnt[i] = 0;
+            }
+        }
+    }
+    __syncthreads();
+
+    const unsigned long long j0 = s.chunk_first[c], j1 = s.chunk_first[c + 1];
+    const unsigned long long bstart = s.bin_start[c];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NWAVES = KB_C_THREADS / 64;
+    const uint32_t bmask = B - 1;
+    uint32_t claimed = 0;
+    bool failed = false;
+    // Wave-uniform loops only: lanes without an entry carry todo = false.  The
+    // wide-key claim never waits inside a divergent loop (see kdf_device.h): a
+    // lane that meets a PENDING slot retries in the next pass of the
+    // wave-uniform `while (__any(todo))`.
+    for (unsigned long long j = j0 + wave; j < j1; j += NWAVES) {
+        const uint32_t r0 = s.chunk_off[j * (KB_F + 1) + f], r1 = s.chunk_off[j * (KB_F + 1) + f + 1];
+        const unsigned long long base = bstart + (j - j0) * (unsigned long long)CHUNK;
+        for (uint32_t i0 = r0; i0 < r1; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            bool todo = i < r1;
+            const uint64_t klo = todo ? s.ent_lo[base + i] : 0;
+            const uint64_t khi = (KW == 2 && todo) ? s.ent_hi[base + i] : 0;
+            const uint64_t h = kdf_hash(klo, khi);
+            const uint64_t home = h >> (64 - plan.log2cap);
+            if (plan.sub_bits && (home >> plan.bucket_bits) != bucket) todo = false;   // sibling bucket's entry
+            if constexpr (MODE == KB_MODE_REPLAY) {
+                const uint64_t slot = kdf_home(t, h);
+                bool ok = true;
+                if constexpr (KW == 1) { if (todo) ok = kdf_add_narrow<true>(t, klo, 1u, slot, t.lo[slot], claimed); }
+                else ok = kdf_add_wide<true>(t, todo, klo, khi, 1u, slot, claimed);
+                if (!ok) failed = true;
+                continue;
+            }
+            if constexpr (KW == 1) {
+                if (!todo) continue;
+                uint32_t sl = (uint32_t)home & bmask;
+                for (uint32_t n = 0;; ++n) {
+                    if (n > bmask) { failed = true; break; }
+                    uint64_t cur = tlo[sl];
+                    if (cur == KDF_EMPTY && MODE == KB_MODE_INSERT) {
+                        cur = atomicCAS((unsigned long long *)&tlo[sl], KDF_EMPTY, klo);
+                        if (cur == KDF_EMPTY) { claimed++; cur = klo; }
+                    }
+                    if (cur == klo) { kb_lds_sat_add(&tcnt[sl], 1u); break; }
+                    if (cur == KDF_EMPTY) break;                         // FILTERED: absent
+                    sl = (sl + 1) & bmask;
+                }
+            } else {
+                // wide: claim hi with PENDING, publish lo, then the final hi (all in LDS)
+                while (__any(todo)) {
+                    if (todo) {
+                        uint32_t sl = (uint32_t)home & bmask;
+                        int res = -1;                                    // -1 probing, 0 done, 1 full, 2 blocked
+                        for (uint32_t n = 0; res < 0; ++n) {
+                            if (n > bmask) { res = 1; break; }
+                            uint64_t chi = __hip_atomic_load(&thi[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (chi == KDF_EMPTY && MODE == KB_MODE_INSERT) {
+                                chi = atomicCAS((unsigned long long *)&thi[sl], KDF_EMPTY, khi | KDF_PENDING);
+                                if (chi == KDF_EMPTY) {
+                                    __hip_atomic_store(&tlo[sl], klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    __hip_atomic_store(&thi[sl], khi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    claimed++;
+                                    kb_lds_sat_add(&tcnt[sl], 1u);
+                                    res = 0; break;
+                                }
+                            }
+                            if (chi == KDF_EMPTY) { res = 0; break; }    // FILTERED: absent
+                            if ((chi & ~KDF_PENDING) == khi) {
+                                if (chi & KDF_PENDING) { res = 2; break; }
+                                const uint64_t clo = __hip_atomic_load(&tlo[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (clo == klo) { kb_lds_sat_add(&tcnt[sl], 1u); res = 0; break; }
+                            }
+                            sl = (sl + 1) & bmask;
+                        }
+                        if (res != 2) { todo = false; if (res == 1) failed = true; }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+    }
+    if (failed) atomicOr(&sh_failed, 1u);
+    if (claimed) atomicAdd(&sh_claimed, claimed);
+    __syncthreads();
+    if constexpr (MODE == KB_MODE_REPLAY) {
+        if (threadIdx.x == 0) {
+            if (sh_failed) atomicOr(&ctl->error, 1u);
+            if (sh_claimed) atomicAdd(&ctl->distinct[(bucket % KDF_SHARDS) * 16], (unsigned long long)sh_claimed);
+        }
+        return;
+    }
+    if (sh_failed) {
+        // leave the bucket untouched in HBM; flag it for replay
+        if (threadIdx.x == 0) {
+            atomicOr(&s.failed[bucket >> 5], 1u << (bucket & 31));
+            atomicAdd(&s.totals[2], 1ull);
+        }
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < B; i += KB_C_THREADS) {
+        if constexpr (MODE == KB_MODE_INSERT) {
+            t.lo[slot0 + i] = tlo[i];
+            if constexpr (KW == 2) t.hi[slot0 + i] = thi[i];
+        }
+        t.cnt[slot0 + i] = tcnt[i];
+    }
+    if (threadIdx.x == 0 && sh_claimed)
+        atomicAdd(&ctl->distinct[(bucket % KDF_SHARDS) * 16], (unsigned long long)sh_claimed);
+}

@@ -108,23 +108,33 @@ __device__ __forceinline__ uint64_t kdf_find_narrow(const KdfTable &t, uint64_t 
 // ---- wide keys (33 <= k <= 63): hi holds 2k-64 <= 62 bits -------------------
 // Claim protocol without a 128-bit CAS: CAS hi EMPTY -> (hi | PENDING), publish
 // lo with a returning atomic (complete at memory before the next instruction
-// issues), then store the final hi.  A prober that sees its hi with PENDING set
-// re-reads until the claimer (which needs no other lane to make progress)
-// clears it.  All shared words are accessed with device-scope atomics.
+// issues), then store the final hi.  All shared words are accessed with
+// device-scope atomics.
+//
+// NO LANE EVER WAITS for another lane inside a divergent loop: a prober that
+// meets a PENDING slot whose hi matches its own returns KDF_BLOCKED, and the
+// caller retries under a wave-uniform `while (__any(todo))` loop
+// (kdf_add_wide).  A spin inside the probe loop deadlocks when the claimer is a
+// lane of the same wave: its publish block leaves the loop, so the compiler may
+// run it only after every lane has left the loop.
+
+#define KDF_OK_ADD  0
+#define KDF_FULL    1
+#define KDF_BLOCKED 2
 
 __device__ __forceinline__ uint64_t kdf_ld(const uint64_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <bool INSERT>
-__device__ __forceinline__ bool kdf_add_wide(const KdfTable &t, uint64_t klo, uint64_t khi,
-                                             uint32_t add, uint64_t slot, uint32_t &claimed) {
+__device__ __forceinline__ int kdf_try_add_wide(const KdfTable &t, uint64_t klo, uint64_t khi,
+                                                uint32_t add, uint64_t slot, uint32_t &claimed) {
     const uint64_t bmask = (1ull << t.bucket_bits) - 1;
     const uint64_t base = slot & ~bmask;
     for (uint64_t i = 0;;) {
         uint64_t chi = INSERT ? kdf_ld(&t.hi[slot]) : t.hi[slot];
         if (chi == KDF_EMPTY) {
-            if (!INSERT) return true;
+            if (!INSERT) return KDF_OK_ADD;
             uint64_t old = atomicCAS((unsigned long long *)&t.hi[slot], KDF_EMPTY, khi | KDF_PENDING);
             if (old == KDF_EMPTY) {
                 uint64_t prev = atomicExch((unsigned long long *)&t.lo[slot], klo);
@@ -132,20 +142,34 @@ __device__ __forceinline__ bool kdf_add_wide(const KdfTable &t, uint64_t klo, ui
                 __hip_atomic_store(&t.hi[slot], khi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 claimed++;
                 if (add) kdf_sat_add(&t.cnt[slot], add);
-                return true;
+                return KDF_OK_ADD;
             }
             chi = old;
         }
         if ((chi & ~KDF_PENDING) == khi) {
-            if (INSERT) {
-                while (chi & KDF_PENDING) { __builtin_amdgcn_s_sleep(1); chi = kdf_ld(&t.hi[slot]); }
-            }
+            if (chi & KDF_PENDING) return KDF_BLOCKED;       // lo not published yet: retry later
             uint64_t clo = INSERT ? kdf_ld(&t.lo[slot]) : t.lo[slot];
-            if (clo == klo) { if (add) kdf_sat_add(&t.cnt[slot], add); return true; }
+            if (clo == klo) { if (add) kdf_sat_add(&t.cnt[slot], add); return KDF_OK_ADD; }
         }
-        if (++i > bmask) return false;
+        if (++i > bmask) return KDF_FULL;
         slot = base | ((slot + 1) & bmask);
     }
+}
+
+// Must be reached by the lanes of a wave together with `todo` telling which of
+// them have a key (divergent callers pass todo = false for the idle lanes).
+template <bool INSERT>
+__device__ __forceinline__ bool kdf_add_wide(const KdfTable &t, bool todo, uint64_t klo, uint64_t khi,
+                                             uint32_t add, uint64_t slot, uint32_t &claimed) {
+    bool ok = true;
+    while (__any(todo)) {
+        if (todo) {
+            const int r = kdf_try_add_wide<INSERT>(t, klo, khi, add, slot, claimed);
+            if (r != KDF_BLOCKED) { todo = false; ok = (r == KDF_OK_ADD); }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return ok;
 }
 
 __device__ __forceinline__ uint64_t kdf_find_wide(const KdfTable &t, uint64_t klo, uint64_t khi) {

@@ -12,6 +12,7 @@
 
 #include "kdf.h"
 #include "kdf_device.h"
+#include "kdf_binned.h"
 
 // sorted export lives in kdf_sort.hip (rocPRIM radix sort)
 int kdf_sort_pairs_device(uint64_t *d_lo, uint64_t *d_hi, uint32_t *d_cnt, uint64_t n,
@@ -70,14 +71,16 @@ __global__ __launch_bounds__(256) void kdf_stream_kernel(
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const bool ok = (valid >> (b + u)) & 1;
-                    if (!ok) continue;
                     if constexpr (MODE == MODE_SCAN) {
+                        if (!ok) continue;
                         uint64_t s = KW == 1 ? kdf_find_narrow(t, klo[u]) : kdf_find_wide(t, klo[u], khi[u]);
                         if (s != ~0ull && t.cnt[s] != 0) hits |= 1ull << (b + u);
                     } else if constexpr (KW == 1) {
+                        if (!ok) continue;
                         if (!kdf_add_narrow<MODE == MODE_INSERT>(t, klo[u], 1u, slot[u], cur[u], claimed)) full = true;
                     } else {
-                        if (!kdf_add_wide<MODE == MODE_INSERT>(t, klo[u], khi[u], 1u, slot[u], claimed)) full = true;
+                        // every lane that reached this batch calls in; idle lanes pass todo = false
+                        if (!kdf_add_wide<MODE == MODE_INSERT>(t, ok, klo[u], khi[u], 1u, slot[u], claimed)) full = true;
                     }
                 }
             }
@@ -105,17 +108,16 @@ __global__ __launch_bounds__(256) void kdf_insert_keys_kernel(
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t claimed = 0;
     bool full = false;
-    if (i < n) {
-        const uint64_t lo = klo[i], hi = KW == 2 ? khi[i] : 0;
+    {
+        const uint64_t lo = i < n ? klo[i] : KDF_EMPTY, hi = (KW == 2 && i < n) ? khi[i] : (KW == 2 ? KDF_EMPTY : 0);
         const bool present = KW == 1 ? (lo != KDF_EMPTY) : (hi != KDF_EMPTY);
-        if (present || !skip_empty) {
-            const uint32_t a = add ? add[i] : 0u;
-            const uint64_t slot = kdf_home(t, kdf_hash(lo, hi));
-            if constexpr (KW == 1) {
-                if (!kdf_add_narrow<true>(t, lo, a, slot, t.lo[slot], claimed)) full = true;
-            } else {
-                if (!kdf_add_wide<true>(t, lo, hi & ~KDF_PENDING, a, slot, claimed)) full = true;
-            }
+        const bool todo = i < n && (present || !skip_empty);
+        const uint32_t a = (todo && add) ? add[i] : 0u;
+        const uint64_t slot = kdf_home(t, kdf_hash(lo, hi));
+        if constexpr (KW == 1) {
+            if (todo && !kdf_add_narrow<true>(t, lo, a, slot, t.lo[slot], claimed)) full = true;
+        } else {
+            if (!kdf_add_wide<true>(t, todo, lo, hi & ~KDF_PENDING, a, slot, claimed)) full = true;
         }
     }
     if (full) atomicOr(&ctl->error, 1u);
@@ -222,6 +224,15 @@ struct kdf_engine {
     // grow-only device staging for the host-buffer entry points
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t stage_bytes[4] = {0, 0, 0, 0};
+    // binned (LDS-bucket) path: scratch + options
+    unsigned long long *kb_small = nullptr;   // hist1 | bin_start | cursor | chunk_first | totals
+    unsigned long long *kb_totals_host = nullptr;   // pinned [4]
+    void *kb_buf[4] = {nullptr, nullptr, nullptr, nullptr};   // ent_lo, ent_hi, chunk_off, failed
+    size_t kb_bytes[4] = {0, 0, 0, 0};
+    uint64_t opt_binned_min_positions = 1ull << 22;  // smaller batches use the direct global-table kernels
+    uint32_t opt_binned_filtered_min_log2cap = 26;   // count --if goes binned only for tables this large
+    int opt_force_path = 0;                          // 0 auto, 1 direct, 2 binned
+    uint64_t stat_binned_passes = 0, stat_replayed_buckets = 0;
     // optional HIP-event timing of the dominant (stream) kernel
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;   // pending start/stop pairs
@@ -261,7 +272,7 @@ static int table_alloc(kdf_engine *h, uint32_t log2cap, KdfTable &t) {
     const uint64_t cap = 1ull << log2cap;
     t = KdfTable{};
     t.log2cap = log2cap;
-    t.bucket_bits = std::min<uint32_t>(log2cap, h->kw == 1 ? 13 : 12);
+    t.bucket_bits = std::min<uint32_t>(log2cap, h->kw == 1 ? 12 : 11);   // 48 / 40 KB of LDS per bucket
     HIPCHK(h, hipMalloc((void **)&t.lo, cap * 8));
     if (h->kw == 2) HIPCHK(h, hipMalloc((void **)&t.hi, cap * 8));
     HIPCHK(h, hipMalloc((void **)&t.cnt, cap * 4));
@@ -379,12 +390,143 @@ static void prof_collect(kdf_engine *h) {
     h->prof_ev.clear(); h->prof_tiles.clear();
 }
 
+// ---------------------------------------------------------------------------
+// binned path (kdf_binned.h)
+
+static int kb_reserve(kdf_engine *h, int i, size_t bytes) {
+    if (h->kb_bytes[i] >= bytes) return KDF_OK;
+    if (h->kb_buf[i]) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->kb_buf[i]); h->kb_buf[i] = nullptr; h->kb_bytes[i] = 0; }
+    const size_t want = bytes + bytes / 16 + 4096;
+    HIPCHK(h, hipMalloc(&h->kb_buf[i], want));
+    h->kb_bytes[i] = want;
+    return KDF_OK;
+}
+
+static KbPlan kb_make_plan(const KdfTable &t) {
+    KbPlan p{};
+    p.log2cap = t.log2cap; p.bucket_bits = t.bucket_bits;
+    const uint32_t nb_bits = t.log2cap - t.bucket_bits;
+    p.c2 = std::min<uint32_t>(KB_F_BITS, nb_bits);
+    p.c1 = std::min<uint32_t>(KB_C1_MAX, nb_bits - p.c2);
+    p.sub_bits = nb_bits - p.c1 - p.c2;
+    return p;
+}
+
+template <int KW>
+static int kb_set_lds_attrs(kdf_engine *h, size_t a1, size_t b, size_t c) {
+    HIPCHK(h, hipFuncSetAttribute((const void *)kb_scatter1_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a1));
+    HIPCHK(h, hipFuncSetAttribute((const void *)kb_finesort_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b));
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_INSERT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c));
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_FILTERED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c));
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_REPLAY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c));
+    return KDF_OK;
+}
+
+static int table_rehash(kdf_engine *h, uint32_t new_log2);
+
+// one pass of the binned pipeline over a device-resident stream
+template <int KW>
+static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases, bool filtered) {
+    constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT, CHUNK = KbCfg<KW>::CHUNK, SLAB = KB_THREADS * WPT;
+    const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
+    if (n_tiles == 0) return KDF_OK;
+    const KbPlan plan = kb_make_plan(h->t);
+    const int nb1 = 1 << KB_C1_MAX;
+    if (!h->kb_small) {
+        HIPCHK(h, hipMalloc((void **)&h->kb_small, (size_t)(4 * (nb1 + 1) + 8) * 8));
+        HIPCHK(h, hipHostMalloc((void **)&h->kb_totals_host, 64));
+    }
+    KbScratch s{};
+    s.hist1 = h->kb_small; s.bin_start = s.hist1 + (nb1 + 1); s.cursor = s.bin_start + (nb1 + 1);
+    s.chunk_first = s.cursor + (nb1 + 1); s.totals = s.chunk_first + (nb1 + 1);
+    const size_t lds_a1 = (size_t)SLAB * 8 * KW + (size_t)(2 * nb1 + 32) * 4 + (size_t)nb1 * 8;
+    const size_t lds_b = (size_t)CHUNK * 8 * KW + (size_t)(2 * KB_F + 32) * 4 + 16;
+    const size_t lds_c = ((size_t)8 * KW + 4) * ((size_t)1 << plan.bucket_bits) + 16;
+    int rc = kb_set_lds_attrs<KW>(h, lds_a1, lds_b, lds_c);
+    if (rc) return rc;
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->prof) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, h->stream); }
+
+    const unsigned grid_a = (unsigned)((n_tiles + (KB_THREADS / TPT) - 1) / (KB_THREADS / TPT));
+    HIPCHK(h, hipMemsetAsync(s.hist1, 0, (size_t)(nb1 + 1) * 8, h->stream));
+    hipLaunchKernelGGL(kb_hist1_kernel<KW>, dim3(grid_a), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s);
+    hipLaunchKernelGGL(kb_scan1_kernel, dim3(1), dim3(KB_THREADS), 0, h->stream, plan, s, (uint32_t)CHUNK, h->ctl);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(h->kb_totals_host, s.totals, 32, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const uint64_t n_entries = h->kb_totals_host[0], n_chunks = h->kb_totals_host[1];
+    if (n_entries == 0) { if (h->prof) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); } return KDF_OK; }
+
+    const uint64_t nb_table = 1ull << (plan.c1 + plan.c2 + plan.sub_bits);
+    if ((rc = kb_reserve(h, 0, n_entries * 8))) return rc;
+    if (KW == 2 && (rc = kb_reserve(h, 1, n_entries * 8))) return rc;
+    if ((rc = kb_reserve(h, 2, n_chunks * (KB_F + 1) * 4))) return rc;
+    const size_t failed_bytes = (size_t)((nb_table + 31) / 32) * 4;
+    if ((rc = kb_reserve(h, 3, failed_bytes))) return rc;
+    s.ent_lo = (uint64_t *)h->kb_buf[0]; s.ent_hi = (uint64_t *)h->kb_buf[1];
+    s.chunk_off = (uint32_t *)h->kb_buf[2]; s.failed = (uint32_t *)h->kb_buf[3];
+    HIPCHK(h, hipMemsetAsync(s.failed, 0, failed_bytes, h->stream));
+
+    hipLaunchKernelGGL(kb_scatter1_kernel<KW>, dim3(grid_a), dim3(KB_THREADS), lds_a1, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s);
+    hipLaunchKernelGGL(kb_finesort_kernel<KW>, dim3((unsigned)n_chunks), dim3(KB_THREADS), lds_b, h->stream, plan, s);
+    const int nonempty = (filtered || h->distinct != 0) ? 1 : 0;
+    if (filtered)
+        hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_FILTERED>), dim3((unsigned)nb_table), dim3(KB_C_THREADS), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty);
+    else
+        hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_INSERT>), dim3((unsigned)nb_table), dim3(KB_C_THREADS), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty);
+    HIPCHK(h, hipGetLastError());
+    if (h->prof) {
+        (void)hipEventRecord(e1, h->stream);
+        h->prof_ev.emplace_back(e0, e1);
+        h->prof_tiles.push_back(n_tiles);
+    }
+    HIPCHK(h, hipMemcpyAsync(h->kb_totals_host, s.totals, 32, hipMemcpyDeviceToHost, h->stream));
+    bool full = false;
+    if ((rc = ctl_sync(h, &full))) return rc;
+    h->stat_binned_passes++;
+    const uint64_t n_failed = h->kb_totals_host[2];
+    if (n_failed == 0) return KDF_OK;
+    if (filtered) return fail(h, KDF_ERR_STATE, "binned count --if: a bucket failed (corrupt table?)");
+    // some buckets overflowed: they are untouched in HBM.  Grow the table so
+    // that even if every entry of the failed buckets were new the load stays
+    // <= 0.5, then replay exactly those buckets through the global-atomic path.
+    h->stat_replayed_buckets += n_failed;
+    const uint64_t worst = h->distinct + std::min<uint64_t>(n_entries, n_failed * ((n_entries / std::max<uint64_t>(nb_table, 1)) * 4 + 4096));
+    uint32_t want = std::max<uint32_t>(h->t.log2cap + 1, cap_log2_for(worst));
+    if ((rc = table_rehash(h, want))) return rc;
+    hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_REPLAY>), dim3((unsigned)nb_table), dim3(KB_C_THREADS), lds_c, h->stream, plan, s, h->t, h->ctl, 1);
+    HIPCHK(h, hipGetLastError());
+    if ((rc = ctl_sync(h, &full))) return rc;
+    if (full) return fail(h, KDF_ERR_TABLE_FULL, "binned count: bucket overflow during replay (capacity 2^%u)", h->t.log2cap);
+    return KDF_OK;
+}
+
+static bool use_binned(const kdf_engine *h, uint64_t n_bases, bool filtered) {
+    if (h->t.log2cap <= h->t.bucket_bits) return false;        // a single bucket: nothing to partition
+    if (h->opt_force_path == 1) return false;
+    if (h->opt_force_path == 2) return true;
+    if (n_bases < h->opt_binned_min_positions) return false;
+    if (filtered && h->t.log2cap < h->opt_binned_filtered_min_log2cap) return false;
+    return true;
+}
+
 // insert-mode count over a device-resident stream.  The stream is walked in
 // chunks sized so that even if every position were a new key the table stays
 // at load <= 0.8; the table doubles when fewer than cap/8 positions fit.
 static int count_insert_dev(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases) {
     if (h->filter_mode) return fail(h, KDF_ERR_STATE, "kdf_count_reads: a filter is loaded; call kdf_clear first");
     const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
+    if (use_binned(h, n_bases, false)) {
+        int rc = h->kw == 1 ? kb_pass<1>(h, d_packed, d_invalid, n_bases, false)
+                            : kb_pass<2>(h, d_packed, d_invalid, n_bases, false);
+        if (rc) return rc;
+        // keep the load <= 0.6 for the next batch
+        while (h->distinct * 10 > h->cap * 6) {
+            if ((rc = table_rehash(h, h->t.log2cap + 1))) return rc;
+        }
+        return KDF_OK;
+    }
     uint64_t tile = 0;
     while (tile < n_tiles) {
         uint64_t room = (h->cap / 10) * 8 > h->distinct ? (h->cap / 10) * 8 - h->distinct : 0;
@@ -410,6 +552,9 @@ static int count_filtered_dev(kdf_engine *h, const uint64_t *d_packed, const uin
     if (!h->filter_mode) return fail(h, KDF_ERR_STATE, "kdf_count_reads_filtered: no filter loaded (kdf_load_filter)");
     const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
     if (n_tiles == 0) return KDF_OK;
+    if (use_binned(h, n_bases, true))
+        return h->kw == 1 ? kb_pass<1>(h, d_packed, d_invalid, n_bases, true)
+                          : kb_pass<2>(h, d_packed, d_invalid, n_bases, true);
     launch_stream<MODE_FILTERED>(h, d_packed, d_invalid, 0, n_tiles, nullptr);
     HIPCHK(h, hipGetLastError());
     return KDF_OK;
@@ -488,6 +633,9 @@ void kdf_destroy(kdf_engine *h) {
     table_free(h->t);
     prof_collect(h);
     for (int i = 0; i < 4; ++i) if (h->stage[i]) (void)hipFree(h->stage[i]);
+    for (int i = 0; i < 4; ++i) if (h->kb_buf[i]) (void)hipFree(h->kb_buf[i]);
+    if (h->kb_small) (void)hipFree(h->kb_small);
+    if (h->kb_totals_host) (void)hipHostFree(h->kb_totals_host);
     if (h->ctl) (void)hipFree(h->ctl);
     if (h->d_out4) (void)hipFree(h->d_out4);
     if (h->h_out4) (void)hipHostFree(h->h_out4);
@@ -845,6 +993,27 @@ int kdf_profile_read(kdf_engine *h, double *kernel_ms, uint64_t *launches, uint6
     if (kernel_ms) *kernel_ms = h->prof_ms;
     if (launches) *launches = h->prof_launches;
     if (positions) *positions = h->prof_positions;
+    return KDF_OK;
+}
+
+int kdf_set_option(kdf_engine *h, const char *name, int64_t value) {
+    if (!h || !name) return fail(h, KDF_ERR_INVALID, "kdf_set_option: NULL argument");
+    const std::string n(name);
+    if (n == "binned_min_positions") h->opt_binned_min_positions = (uint64_t)value;
+    else if (n == "binned_filtered_min_log2cap") h->opt_binned_filtered_min_log2cap = (uint32_t)value;
+    else if (n == "force_path") h->opt_force_path = (int)value;
+    else return fail(h, KDF_ERR_INVALID, "kdf_set_option: unknown option %s", name);
+    return KDF_OK;
+}
+
+int kdf_get_stat(kdf_engine *h, const char *name, int64_t *value) {
+    if (!h || !name || !value) return fail(h, KDF_ERR_INVALID, "kdf_get_stat: NULL argument");
+    const std::string n(name);
+    if (n == "binned_passes") *value = (int64_t)h->stat_binned_passes;
+    else if (n == "replayed_buckets") *value = (int64_t)h->stat_replayed_buckets;
+    else if (n == "log2cap") *value = h->t.log2cap;
+    else if (n == "bucket_bits") *value = h->t.bucket_bits;
+    else return fail(h, KDF_ERR_INVALID, "kdf_get_stat: unknown stat %s", name);
     return KDF_OK;
 }
 

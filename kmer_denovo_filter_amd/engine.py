@@ -83,6 +83,15 @@ class KmerEngine:
         self._ck(self._lib.kdf_stats(self._h, byref(c), byref(d), byref(w)))
         return c.value, d.value, w.value
 
+    def set_option(self, name: str, value: int):
+        self._ck(self._lib.kdf_set_option(self._h, name.encode(), int(value)))
+
+    def get_stat(self, name: str) -> int:
+        from ctypes import c_int64
+        v = c_int64(0)
+        self._ck(self._lib.kdf_get_stat(self._h, name.encode(), byref(v)))
+        return v.value
+
     def profile(self, enable: bool = True):
         self._ck(self._lib.kdf_profile(self._h, 1 if enable else 0))
 

@@ -116,3 +116,76 @@ def test_errors_are_loud():
         e.load_filter(np.array([5], np.uint64))
         with pytest.raises(KdfError):
             e.count(ReadStream.from_strings(["ACGT" * 20]))            # filter mode: insert refused
+
+
+# --------------------------------------------------------------------------
+# binned (LDS-bucket) pipeline, forced on small inputs
+# --------------------------------------------------------------------------
+
+@pytest.mark.parametrize("k,hint", [(31, 1 << 12), (31, 1 << 17), (21, 1 << 20), (47, 1 << 13), (63, 1 << 17)])
+def test_binned_count_matches_oracle(oracle, k, hint):
+    """force_path=2: every count call goes through A0/A1/B/C.  Small hints make
+    buckets overflow, which exercises the transactional failure + replay."""
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    rng = np.random.default_rng(900 + k + hint)
+    genome = rng.integers(0, 4, 60000).astype(np.uint8)
+    reads = rand_reads(rng, 3000, 0, 300, genome=genome) + ["", "A" * 500, "N" * 70, "ACGT" * 80]
+    t, (lo, hi, cnt) = oracle_sorted(oracle, k, reads)
+    with KmerEngine(k, capacity_hint=hint) as e:
+        e.set_option("force_path", 2)
+        st = ReadStream.from_strings(reads)
+        half = len(reads) // 2
+        # two batches: the second one finds a non-empty table
+        e.count(ReadStream.from_strings(reads[:half]))
+        e.count(ReadStream.from_strings(reads[half:]))
+        assert e.get_stat("binned_passes") == 2
+        glo, ghi, gcnt = e.export_ge(0)
+        cap, distinct, windows = e.stats()
+        assert windows == oracle.count_windows(reads, k)
+        assert distinct == len(lo)
+        np.testing.assert_array_equal(glo, lo)
+        np.testing.assert_array_equal(ghi, hi)
+        np.testing.assert_array_equal(gcnt, cnt)
+        if hint <= 1 << 13:
+            assert e.get_stat("replayed_buckets") > 0     # the small table really overflowed
+        np.testing.assert_array_equal(e.query(lo[::7], hi[::7]), cnt[::7])
+
+
+@pytest.mark.parametrize("k", [31, 55])
+def test_binned_count_filtered(oracle, k):
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    rng = np.random.default_rng(77 + k)
+    genome = rng.integers(0, 4, 50000).astype(np.uint8)
+    child = rand_reads(rng, 1500, 50, 260, genome=genome)
+    parent = rand_reads(rng, 3000, 0, 260, genome=genome)
+    _, (lo, hi, _) = oracle_sorted(oracle, k, child)
+    sel = rng.random(len(lo)) < 0.4
+    flo, fhi = lo[sel], hi[sel]
+    ot = oracle.OracleTable(k, 1 << 12).load_filter(flo, fhi).count_reads_filtered(parent)
+    with KmerEngine(k) as e:
+        e.load_filter(flo, fhi)
+        e.set_option("force_path", 2)
+        e.count_filtered(ReadStream.from_strings(parent[:1000]))
+        e.count_filtered(ReadStream.from_strings(parent[1000:]))
+        assert e.get_stat("binned_passes") == 2
+        np.testing.assert_array_equal(e.query(lo, hi), ot.query(lo, hi))
+        glo, _, gcnt = e.export_ge(0)
+        olo, _, ocnt = ot.export_ge(0)
+        np.testing.assert_array_equal(glo, olo)
+        np.testing.assert_array_equal(gcnt, ocnt)
+
+
+def test_binned_skewed_multiplicity(oracle):
+    """Heavy hitters (poly-A, short tandem repeats) land in one bucket: chunks
+    and buckets must cope with runs far above the mean."""
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    rng = np.random.default_rng(5)
+    reads = ["A" * 300] * 400 + ["ACACACACAC" * 30] * 300 + rand_reads(rng, 500, 100, 200)
+    t, (lo, hi, cnt) = oracle_sorted(oracle, 31, reads)
+    with KmerEngine(31, capacity_hint=1 << 16) as e:
+        e.set_option("force_path", 2)
+        e.count(ReadStream.from_strings(reads))
+        glo, _, gcnt = e.export_ge(0)
+        np.testing.assert_array_equal(glo, lo)
+        np.testing.assert_array_equal(gcnt, cnt)
+        assert int(gcnt.max()) == 400 * 270
