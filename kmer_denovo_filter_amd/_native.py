@@ -67,11 +67,35 @@ class KdfError(RuntimeError):
         self.code = code
 
 
+def _preload_torch_hip():
+    """PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64.  If
+    libkdf.so pulled /opt/rocm's copies first, a later `import torch` would load
+    a SECOND HSA runtime into the process and find no device.  Loading torch's
+    copies first (same SONAMEs) makes both sides share one runtime, in either
+    import order.  torch itself is not imported and the GPU is not touched."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load() -> ctypes.CDLL:
     """Load libkdf.so, building it first if the source tree has hipcc and no .so."""
     global _lib
     if _lib is not None:
         return _lib
+    _preload_torch_hip()
     if not os.path.exists(LIB_PATH):
         from .build import build_native
         try:

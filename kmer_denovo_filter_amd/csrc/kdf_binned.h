@@ -28,6 +28,7 @@
 #define KB_F         (1 << KB_F_BITS)
 #define KB_C1_MAX    9                   // coarse bins <= 512
 #define KB_C_THREADS 512                 // bucket kernel
+#define KB_C_RUNS    256                 // runs (chunks of the coarse bin) staged per round
 
 template <int KW> struct KbCfg;
 template <> struct KbCfg<1> { static constexpr int WPT = 16, CHUNK = 16384; };   // 8-byte entries: 128 KB of LDS
@@ -47,6 +48,7 @@ struct KbScratch {
     unsigned long long *cursor;     // [2^c1]
     unsigned long long *chunk_first;// [2^c1 + 1]
     unsigned long long *totals;     // [4]: n_entries, n_chunks, n_failed, claimed
+    unsigned int *failed_flag;      // [1]: set when the scatter pass disagrees with the histogram pass
     uint32_t *chunk_off;            // [n_chunks][2^c2 + 1]
     uint32_t *failed;               // bitmap over TABLE buckets (2^(c1+c2+sub_bits) bits)
     uint64_t *ent_lo;               // entries (keys); wide: lo words
@@ -89,28 +91,38 @@ __device__ __forceinline__ uint32_t kb_block_exscan(uint32_t v, uint32_t *wsum /
 template <int KW>
 struct KbWindows {
     static constexpr int WPT = KbCfg<KW>::WPT;
-    static constexpr int NW = KW == 1 ? 3 : 4;
-    uint64_t w[NW];
+    static constexpr int NE = KW == 1 ? 2 : 3;
+    uint64_t e[NE];       // the stream from this thread's first position on (bit 0 = its first base)
     uint32_t valid;       // WPT bits
-    int p0;               // first local position of this thread inside the tile
     uint64_t kmask;
     int k;
+    // The words are pre-shifted once so that window u is taken with COMPILE-TIME
+    // shifts (a runtime position would index the word array dynamically).
     __device__ __forceinline__ void load(const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid,
                                          uint64_t tile, uint64_t n_tiles, int part, int k_) {
-        k = k_; p0 = part * WPT; valid = 0;
+        k = k_; valid = 0;
+        const int p0 = part * WPT;
         kmask = (k >= 32) ? ~0ull : ((1ull << (2 * k)) - 1);
         if (tile < n_tiles) {
             const uint64_t v = kdf_valid_windows(invalid[tile], invalid[tile + 1], k);
             valid = (uint32_t)((v >> p0) & ((1ull << WPT) - 1));
             if (valid) {
+                const uint64_t *src = packed + tile * 2 + (p0 >> 5);
+                const int sh = (p0 & 31) * 2;
+                uint64_t w[NE + 1];
 #pragma unroll
-                for (int i = 0; i < NW; ++i) w[i] = packed[tile * 2 + i];
+                for (int i = 0; i <= NE; ++i) w[i] = src[i];     // within the padded tail (kdf_stream_words)
+#pragma unroll
+                for (int i = 0; i < NE; ++i) e[i] = kdf_funnel(w[i], w[i + 1], sh);
             }
         }
     }
-    __device__ __forceinline__ void key(int u, uint64_t &lo, uint64_t &hi) const {
-        if constexpr (KW == 1) { lo = kdf_window_narrow(w, p0 + u, k, kmask); hi = 0; }
-        else kdf_window_wide(w, p0 + u, k, lo, hi);
+    __device__ __forceinline__ void key(int u, uint64_t &lo, uint64_t &hi) const {   // u: compile-time
+        if constexpr (KW == 1) {
+            lo = kdf_canon_narrow(kdf_funnel(e[0], e[1], 2 * u), k, kmask); hi = 0;
+        } else {
+            kdf_canon_wide(kdf_funnel(e[0], e[1], 2 * u), kdf_funnel(e[1], e[2], 2 * u), k, lo, hi);
+        }
     }
 };
 
@@ -151,7 +163,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scan1_kernel(KbPlan plan, KbScr
             acc += n; cacc += (n + chunk - 1) / chunk;
         }
         a[nb] = acc; c[nb] = cacc;
-        s.totals[0] = acc; s.totals[1] = cacc; s.totals[2] = 0; s.totals[3] = 0;
+        s.totals[0] = acc; s.totals[1] = cacc; s.totals[2] = 0; s.totals[3] = 0; s.failed_flag[0] = 0;
         if (acc) atomicAdd(&ctl->windows[0], acc);
     }
     __syncthreads();
@@ -199,7 +211,11 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
         const uint32_t ex = kb_block_exscan(v, wsum, &total);
         if (threadIdx.x < nb) {
             offs[threadIdx.x] = ex;
-            gbase[threadIdx.x] = v ? atomicAdd(&s.cursor[threadIdx.x], (unsigned long long)v) : 0ull;
+            unsigned long long g = v ? atomicAdd(&s.cursor[threadIdx.x], (unsigned long long)v) : 0ull;
+            // guard: the histogram pass sized this bin; if the stream changed
+            // between the two passes (caller error) refuse to write past it
+            if (v && g + v > s.bin_start[threadIdx.x + 1]) { g = ~0ull; atomicOr(&s.failed_flag[0], 1u); }
+            gbase[threadIdx.x] = g;
         }
     }
     __syncthreads();
@@ -216,6 +232,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
     for (uint32_t i = threadIdx.x; i < total; i += KB_THREADS) {
         const uint64_t lo = slo[i], hi = KW == 2 ? shi[i] : 0;
         const uint32_t bin = kb_coarse(plan, kdf_hash(lo, hi));
+        if (gbase[bin] == ~0ull) continue;
         const unsigned long long dst = gbase[bin] + (i - offs[bin]);
         s.ent_lo[dst] = lo;
         if constexpr (KW == 2) s.ent_hi[dst] = hi;
@@ -320,6 +337,9 @@ __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
     uint64_t *thi = KW == 2 ? tlo + B : nullptr;              // [B] wide
     uint32_t *tcnt = (uint32_t *)(smem + (size_t)B * 8 * KW); // [B]
     uint32_t &sh_failed = tcnt[B], &sh_claimed = tcnt[B + 1];
+    uint32_t *wsum = tcnt + B + 2;                            // [32]
+    uint32_t *run_pref = wsum + 32;                           // [KB_C_RUNS] exclusive prefix of run lengths
+    unsigned long long *run_first = (unsigned long long *)(run_pref + KB_C_RUNS);   // [KB_C_RUNS] (B + 34 + KB_C_RUNS is even: 8-aligned)
 
     // `plan` describes the table the partition was built for.  In MODE_REPLAY
     // that is the OLD geometry (the host has grown the table since) and `t` is
@@ -351,23 +371,50 @@ __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
 
     const unsigned long long j0 = s.chunk_first[c], j1 = s.chunk_first[c + 1];
     const unsigned long long bstart = s.bin_start[c];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int NWAVES = KB_C_THREADS / 64;
     const uint32_t bmask = B - 1;
     uint32_t claimed = 0;
     bool failed = false;
-    // Wave-uniform loops only: lanes without an entry carry todo = false.  The
-    // wide-key claim never waits inside a divergent loop (see kdf_device.h): a
-    // lane that meets a PENDING slot retries in the next pass of the
-    // wave-uniform `while (__any(todo))`.
-    for (unsigned long long j = j0 + wave; j < j1; j += NWAVES) {
-        const uint32_t r0 = s.chunk_off[j * (KB_F + 1) + f], r1 = s.chunk_off[j * (KB_F + 1) + f + 1];
-        const unsigned long long base = bstart + (j - j0) * (unsigned long long)CHUNK;
-        for (uint32_t i0 = r0; i0 < r1; i0 += 64) {
-            const uint32_t i = i0 + lane;
-            bool todo = i < r1;
-            const uint64_t klo = todo ? s.ent_lo[base + i] : 0;
-            const uint64_t khi = (KW == 2 && todo) ? s.ent_hi[base + i] : 0;
+    // Runs of this bucket: one per chunk of its coarse bin.  Their bounds are
+    // fetched by all threads at once (one global latency, not one per run) and
+    // laid out in LDS as a flat work list; threads then take entries round
+    // robin, so every lane is busy whatever the run lengths are.
+    for (unsigned long long jb = j0; jb < j1; jb += KB_C_RUNS) {
+        uint32_t len = 0; unsigned long long first = 0;
+        {
+            const unsigned long long j = jb + threadIdx.x;
+            if (threadIdx.x < KB_C_RUNS && j < j1) {
+                const uint32_t r0 = s.chunk_off[j * (KB_F + 1) + f], r1 = s.chunk_off[j * (KB_F + 1) + f + 1];
+                len = r1 - r0;
+                first = bstart + (j - j0) * (unsigned long long)CHUNK + r0;
+            }
+        }
+        uint32_t total = 0;
+        const uint32_t ex = kb_block_exscan(len, wsum, &total);
+        if (threadIdx.x < KB_C_RUNS) { run_pref[threadIdx.x] = ex; run_first[threadIdx.x] = first; }
+        __syncthreads();
+        const uint32_t nruns = (uint32_t)((j1 - jb) < (unsigned long long)KB_C_RUNS ? (j1 - jb) : (unsigned long long)KB_C_RUNS);
+        constexpr int EPB = 16;    // entries per thread per batch: EPB loads in flight per lane
+        for (uint32_t e0 = 0; e0 < total; e0 += KB_C_THREADS * EPB) {   // wave-uniform trip count
+          uint64_t bklo[EPB], bkhi[KW == 2 ? EPB : 1];
+#pragma unroll
+          for (int q = 0; q < EPB; ++q) {
+            const uint32_t ei = e0 + q * KB_C_THREADS + threadIdx.x;
+            bklo[q] = 0; if constexpr (KW == 2) bkhi[q] = 0;
+            if (ei < total) {
+                // largest r with run_pref[r] <= ei (prefixes are non-decreasing, so
+                // among equal prefixes the last -- the non-empty run -- wins)
+                uint32_t lo_ = 0, hi_ = nruns;
+                while (hi_ - lo_ > 1) { const uint32_t mid = (lo_ + hi_) >> 1; if (run_pref[mid] <= ei) lo_ = mid; else hi_ = mid; }
+                const unsigned long long src = run_first[lo_] + (ei - run_pref[lo_]);
+                bklo[q] = s.ent_lo[src];
+                if constexpr (KW == 2) bkhi[q] = s.ent_hi[src];
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < EPB; ++q) {
+            const uint32_t ei = e0 + q * KB_C_THREADS + threadIdx.x;
+            bool todo = ei < total;
+            const uint64_t klo = bklo[q], khi = KW == 2 ? bkhi[q] : 0;
             const uint64_t h = kdf_hash(klo, khi);
             const uint64_t home = h >> (64 - plan.log2cap);
             if (plan.sub_bits && (home >> plan.bucket_bits) != bucket) todo = false;   // sibling bucket's entry
@@ -394,7 +441,9 @@ __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
                     sl = (sl + 1) & bmask;
                 }
             } else {
-                // wide: claim hi with PENDING, publish lo, then the final hi (all in LDS)
+                // wide: claim hi with PENDING, publish lo, then the final hi (all in LDS).
+                // No lane waits inside a divergent loop (kdf_device.h): a lane that meets
+                // a PENDING slot retries in the next pass of this wave-uniform loop.
                 while (__any(todo)) {
                     if (todo) {
                         uint32_t sl = (uint32_t)home & bmask;
@@ -425,7 +474,9 @@ __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
                     __builtin_amdgcn_wave_barrier();
                 }
             }
+          }
         }
+        __syncthreads();       // run_pref / run_first are rewritten by the next round
     }
     if (failed) atomicOr(&sh_failed, 1u);
     if (claimed) atomicAdd(&sh_claimed, claimed);
@@ -438,10 +489,18 @@ __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
         return;
     }
     if (sh_failed) {
-        // leave the bucket untouched in HBM; flag it for replay
+        // leave the bucket as it was in HBM; flag it for replay.  A lazily
+        // cleared table holds garbage there: write an empty slice instead.
         if (threadIdx.x == 0) {
             atomicOr(&s.failed[bucket >> 5], 1u << (bucket & 31));
             atomicAdd(&s.totals[2], 1ull);
+        }
+        if (!table_nonempty) {
+            for (uint32_t i = threadIdx.x; i < B; i += KB_C_THREADS) {
+                t.lo[slot0 + i] = KDF_EMPTY;
+                if constexpr (KW == 2) t.hi[slot0 + i] = KDF_EMPTY;
+                t.cnt[slot0 + i] = 0;
+            }
         }
         return;
     }

@@ -52,7 +52,8 @@ struct KdfTable {
 struct KdfCtl {            // device-resident control block (one per engine)
     unsigned long long distinct[KDF_SHARDS * 16];  // one 128-B line per shard
     unsigned long long windows[KDF_SHARDS * 16];
-    unsigned long long cursor;                     // export append cursor / counters
+    unsigned long long tally[KDF_SHARDS * 16];     // sharded count-only tally (dump -L counting pass)
+    unsigned long long cursor;                     // export append cursor
     unsigned int error;                            // != 0: a bucket overflowed
     unsigned int pad;
 };
@@ -216,6 +217,31 @@ __device__ __forceinline__ uint64_t kdf_valid_windows(uint64_t m0, uint64_t m1, 
 template <int KW> struct KdfKey;
 template <> struct KdfKey<1> { uint64_t lo; };
 template <> struct KdfKey<2> { uint64_t lo, hi; };
+
+// canonical key from an extracted window E (base j of the window in bits 2j)
+__device__ __forceinline__ uint64_t kdf_canon_narrow(uint64_t e, int k, uint64_t kmask) {
+    e &= kmask;
+    const uint64_t rc = ~e & kmask;
+    const uint64_t fwd = kdf_rev2(e) >> (64 - 2 * k);
+    return fwd < rc ? fwd : rc;
+}
+__device__ __forceinline__ void kdf_canon_wide(uint64_t e0, uint64_t e1, int k, uint64_t &klo, uint64_t &khi) {
+    const int hb = 2 * k - 64;                         // bits used in the high word, 2..62
+    const uint64_t hmask = (1ull << hb) - 1;
+    e1 &= hmask;
+    const uint64_t rlo = ~e0, rhi = ~e1 & hmask;
+    const uint64_t f1 = kdf_rev2(e0), f0 = kdf_rev2(e1);
+    const int s = 128 - 2 * k;                          // 2..62
+    const uint64_t flo = (f0 >> s) | (f1 << (64 - s));
+    const uint64_t fhi = f1 >> s;
+    const bool fw = (fhi < rhi) || (fhi == rhi && flo < rlo);
+    klo = fw ? flo : rlo;
+    khi = fw ? fhi : rhi;
+}
+// (hi:lo) >> sh, low 64 bits; sh in 0..63
+__device__ __forceinline__ uint64_t kdf_funnel(uint64_t lo, uint64_t hi, int sh) {
+    return sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+}
 
 // canonical key of the window starting at local position p (0..63), narrow.
 __device__ __forceinline__ uint64_t kdf_window_narrow(const uint64_t (&w)[3], int p, int k, uint64_t kmask) {

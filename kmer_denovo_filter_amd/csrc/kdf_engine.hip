@@ -156,22 +156,38 @@ __global__ __launch_bounds__(256) void kdf_export_kernel(
     const uint64_t first = wave * (KDF_EXPORT_ROWS * 64);
     if (first >= cap) return;
     uint32_t mine = 0;
+    if (!WRITE && min_count >= 1 && first + KDF_EXPORT_ROWS * 64 <= cap) {
+        // count > 0 implies the slot is occupied: stream the counts array only, 16 B per lane
+        const uint4 *c4 = (const uint4 *)(t.cnt + first);
+#pragma unroll
+        for (int r = 0; r < KDF_EXPORT_ROWS / 4; ++r) {
+            const uint4 v = c4[r * 64 + lane];
+            mine += (v.x >= min_count) + (v.y >= min_count) + (v.z >= min_count) + (v.w >= min_count);
+        }
+    } else
 #pragma unroll 4
     for (int r = 0; r < KDF_EXPORT_ROWS; ++r) {
         const uint64_t i = first + (uint64_t)r * 64 + lane;
         if (i < cap) {
-            const bool occ = KW == 1 ? (t.lo[i] != KDF_EMPTY) : (t.hi[i] != KDF_EMPTY);
-            mine += (occ && t.cnt[i] >= min_count) ? 1u : 0u;
+            if (min_count >= 1) {          // count > 0 implies the slot is occupied: counts array only
+                mine += t.cnt[i] >= min_count ? 1u : 0u;
+            } else {
+                const bool occ = KW == 1 ? (t.lo[i] != KDF_EMPTY) : (t.hi[i] != KDF_EMPTY);
+                mine += occ ? 1u : 0u;
+            }
         }
     }
     uint32_t tot = mine;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
     if (tot == 0) return;
+    if (!WRITE) {      // counting pass: no positions needed, spread the adds over 64 lines
+        if (lane == 0) atomicAdd(&ctl->tally[(wave % KDF_SHARDS) * 16], (unsigned long long)tot);
+        return;
+    }
     unsigned long long base = 0;
     if (lane == 0) base = atomicAdd(&ctl->cursor, (unsigned long long)tot);
     base = __shfl(base, 0);
-    if (!WRITE) return;
     for (int r = 0; r < KDF_EXPORT_ROWS; ++r) {
         const uint64_t i = first + (uint64_t)r * 64 + lane;
         bool keep = false; uint64_t lo = 0, hi = 0; uint32_t c = 0;
@@ -197,10 +213,10 @@ __global__ __launch_bounds__(256) void kdf_export_kernel(
 
 __global__ void kdf_ctl_reduce_kernel(KdfCtl *ctl, unsigned long long *out3) {
     // out3 = {distinct, windows, error}; single wave
-    unsigned long long d = ctl->distinct[threadIdx.x * 16], w = ctl->windows[threadIdx.x * 16];
+    unsigned long long d = ctl->distinct[threadIdx.x * 16], w = ctl->windows[threadIdx.x * 16], y = ctl->tally[threadIdx.x * 16];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { d += __shfl_down(d, o); w += __shfl_down(w, o); }
-    if (threadIdx.x == 0) { out3[0] = d; out3[1] = w; out3[2] = ctl->error; out3[3] = ctl->cursor; }
+    for (int o = 32; o > 0; o >>= 1) { d += __shfl_down(d, o); w += __shfl_down(w, o); y += __shfl_down(y, o); }
+    if (threadIdx.x == 0) { out3[0] = d; out3[1] = w; out3[2] = ctl->error; out3[3] = ctl->cursor + y; }
 }
 
 // ===========================================================================
@@ -221,6 +237,7 @@ struct kdf_engine {
     uint64_t distinct = 0;        // host mirror after the last sync
     uint64_t windows = 0;
     bool filter_mode = false;
+    bool lazy_empty = false;      // logically empty, HBM slices not yet reset (see kdf_clear)
     // grow-only device staging for the host-buffer entry points
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t stage_bytes[4] = {0, 0, 0, 0};
@@ -288,6 +305,17 @@ static void table_free(KdfTable &t) {
     t = KdfTable{};
 }
 
+// kdf_clear defers the 12 B/slot memset: a binned insert into an empty table
+// rewrites every bucket anyway.  Everything else calls this first.
+static int materialize(kdf_engine *h) {
+    if (!h->lazy_empty) return KDF_OK;
+    HIPCHK(h, hipMemsetAsync(h->t.lo, 0xFF, h->cap * 8, h->stream));
+    if (h->kw == 2) HIPCHK(h, hipMemsetAsync(h->t.hi, 0xFF, h->cap * 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->t.cnt, 0, h->cap * 4, h->stream));
+    h->lazy_empty = false;
+    return KDF_OK;
+}
+
 static int stage_reserve(kdf_engine *h, int i, size_t bytes) {
     if (h->stage_bytes[i] >= bytes) return KDF_OK;
     if (h->stage[i]) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->stage[i]); h->stage[i] = nullptr; h->stage_bytes[i] = 0; }
@@ -313,7 +341,7 @@ static int ctl_sync(kdf_engine *h, bool *table_full, uint64_t *cursor = nullptr)
 static int ctl_reset(kdf_engine *h, bool keep_windows) {
     if (keep_windows) {
         HIPCHK(h, hipMemsetAsync(h->ctl->distinct, 0, sizeof(h->ctl->distinct), h->stream));
-        HIPCHK(h, hipMemsetAsync(&h->ctl->cursor, 0, 16, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->ctl->tally, 0, sizeof(h->ctl->tally) + 16, h->stream));
     } else {
         HIPCHK(h, hipMemsetAsync(h->ctl, 0, sizeof(KdfCtl), h->stream));
     }
@@ -325,6 +353,7 @@ static int by_width(kdf_engine *h, F &&f) { return h->kw == 1 ? f(std::integral_
 
 // rehash the live table into one with 2^new_log2 slots
 static int table_rehash(kdf_engine *h, uint32_t new_log2) {
+    { int rc0 = materialize(h); if (rc0) return rc0; }
     KdfTable nt;
     int rc = table_alloc(h, new_log2, nt);
     if (rc) { table_free(nt); return rc; }
@@ -433,15 +462,16 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     const KbPlan plan = kb_make_plan(h->t);
     const int nb1 = 1 << KB_C1_MAX;
     if (!h->kb_small) {
-        HIPCHK(h, hipMalloc((void **)&h->kb_small, (size_t)(4 * (nb1 + 1) + 8) * 8));
-        HIPCHK(h, hipHostMalloc((void **)&h->kb_totals_host, 64));
+        HIPCHK(h, hipMalloc((void **)&h->kb_small, (size_t)(4 * (nb1 + 1) + 16) * 8));
+        HIPCHK(h, hipHostMalloc((void **)&h->kb_totals_host, 128));
     }
     KbScratch s{};
     s.hist1 = h->kb_small; s.bin_start = s.hist1 + (nb1 + 1); s.cursor = s.bin_start + (nb1 + 1);
     s.chunk_first = s.cursor + (nb1 + 1); s.totals = s.chunk_first + (nb1 + 1);
+    s.failed_flag = (unsigned int *)(s.totals + 8);
     const size_t lds_a1 = (size_t)SLAB * 8 * KW + (size_t)(2 * nb1 + 32) * 4 + (size_t)nb1 * 8;
     const size_t lds_b = (size_t)CHUNK * 8 * KW + (size_t)(2 * KB_F + 32) * 4 + 16;
-    const size_t lds_c = ((size_t)8 * KW + 4) * ((size_t)1 << plan.bucket_bits) + 16;
+    const size_t lds_c = ((size_t)8 * KW + 4) * ((size_t)1 << plan.bucket_bits) + (2 + 32 + KB_C_RUNS) * 4 + (size_t)KB_C_RUNS * 8;
     int rc = kb_set_lds_attrs<KW>(h, lds_a1, lds_b, lds_c);
     if (rc) return rc;
 
@@ -470,7 +500,8 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
 
     hipLaunchKernelGGL(kb_scatter1_kernel<KW>, dim3(grid_a), dim3(KB_THREADS), lds_a1, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s);
     hipLaunchKernelGGL(kb_finesort_kernel<KW>, dim3((unsigned)n_chunks), dim3(KB_THREADS), lds_b, h->stream, plan, s);
-    const int nonempty = (filtered || h->distinct != 0) ? 1 : 0;
+    if (filtered && (rc = materialize(h))) return rc;
+    const int nonempty = h->lazy_empty ? 0 : 1;   // 0: kernel C rewrites every bucket (this IS the clear)
     if (filtered)
         hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_FILTERED>), dim3((unsigned)nb_table), dim3(KB_C_THREADS), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty);
     else
@@ -481,10 +512,14 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
         h->prof_ev.emplace_back(e0, e1);
         h->prof_tiles.push_back(n_tiles);
     }
-    HIPCHK(h, hipMemcpyAsync(h->kb_totals_host, s.totals, 32, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->kb_totals_host, s.totals, 72, hipMemcpyDeviceToHost, h->stream));
     bool full = false;
     if ((rc = ctl_sync(h, &full))) return rc;
     h->stat_binned_passes++;
+    h->lazy_empty = false;
+    if (((unsigned int *)(h->kb_totals_host + 8))[0])
+        return fail(h, KDF_ERR_STATE, "binned count: the read stream changed while it was being counted "
+                                      "(is another stream still writing it? synchronise before the call)");
     const uint64_t n_failed = h->kb_totals_host[2];
     if (n_failed == 0) return KDF_OK;
     if (filtered) return fail(h, KDF_ERR_STATE, "binned count --if: a bucket failed (corrupt table?)");
@@ -527,6 +562,7 @@ static int count_insert_dev(kdf_engine *h, const uint64_t *d_packed, const uint6
         }
         return KDF_OK;
     }
+    { int rc0 = materialize(h); if (rc0) return rc0; }
     uint64_t tile = 0;
     while (tile < n_tiles) {
         uint64_t room = (h->cap / 10) * 8 > h->distinct ? (h->cap / 10) * 8 - h->distinct : 0;
@@ -552,6 +588,7 @@ static int count_filtered_dev(kdf_engine *h, const uint64_t *d_packed, const uin
     if (!h->filter_mode) return fail(h, KDF_ERR_STATE, "kdf_count_reads_filtered: no filter loaded (kdf_load_filter)");
     const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
     if (n_tiles == 0) return KDF_OK;
+    { int rc0 = materialize(h); if (rc0) return rc0; }
     if (use_binned(h, n_bases, true))
         return h->kw == 1 ? kb_pass<1>(h, d_packed, d_invalid, n_bases, true)
                           : kb_pass<2>(h, d_packed, d_invalid, n_bases, true);
@@ -660,12 +697,10 @@ int kdf_synchronize(kdf_engine *h) {
 int kdf_clear(kdf_engine *h) {
     if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMemsetAsync(h->t.lo, 0xFF, h->cap * 8, h->stream));
-    if (h->kw == 2) HIPCHK(h, hipMemsetAsync(h->t.hi, 0xFF, h->cap * 8, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->t.cnt, 0, h->cap * 4, h->stream));
     int rc = ctl_reset(h, false);
     if (rc) return rc;
     h->distinct = 0; h->windows = 0; h->filter_mode = false;
+    h->lazy_empty = true;
     return KDF_OK;
 }
 
@@ -723,8 +758,9 @@ int kdf_load_filter(kdf_engine *h, const uint64_t *keys_lo, const uint64_t *keys
         if ((rc = table_alloc(h, want, h->t))) return rc;
         h->cap = 1ull << want;
         if ((rc = ctl_reset(h, false))) return rc;
-        h->distinct = 0; h->windows = 0;
+        h->distinct = 0; h->windows = 0; h->lazy_empty = false; h->filter_mode = false;
     } else if ((rc = kdf_clear(h))) return rc;
+    if ((rc = materialize(h))) return rc;
     h->filter_mode = true;
     if (n == 0) return KDF_OK;
     if ((rc = stage_reserve(h, 2, n * 8))) return rc;
@@ -751,8 +787,9 @@ int kdf_load_filter(kdf_engine *h, const uint64_t *keys_lo, const uint64_t *keys
 // pairs fit at load <= 0.5 even if all of them are new
 static int add_pairs_dev(kdf_engine *h, const uint64_t *d_lo, const uint64_t *d_hi, const uint32_t *d_cnt, uint64_t n) {
     if (n == 0) return KDF_OK;
-    int rc = ctl_sync(h, nullptr);
+    int rc = materialize(h);
     if (rc) return rc;
+    if ((rc = ctl_sync(h, nullptr))) return rc;
     const uint32_t want = cap_log2_for(h->distinct + n);
     if (want > h->t.log2cap && (rc = table_rehash(h, want))) return rc;
     const unsigned blocks = (unsigned)((n + 255) / 256);
@@ -820,6 +857,7 @@ int kdf_query_dev(kdf_engine *h, const void *d_keys_lo, const void *d_keys_hi, u
     if (n == 0) return KDF_OK;
     if (!d_keys_lo || !d_counts_out || (h->kw == 2 && !d_keys_hi)) return fail(h, KDF_ERR_INVALID, "kdf_query_dev: NULL pointer");
     HIPCHK(h, hipSetDevice(h->device));
+    { int rc0 = materialize(h); if (rc0) return rc0; }
     const unsigned blocks = (unsigned)((n + 255) / 256);
     if (h->kw == 1)
         hipLaunchKernelGGL(kdf_query_kernel<1>, dim3(blocks), dim3(256), 0, h->stream,
@@ -852,7 +890,8 @@ int kdf_query(kdf_engine *h, const uint64_t *keys_lo, const uint64_t *keys_hi, u
 
 static int export_pass(kdf_engine *h, uint32_t min_count, bool write, uint64_t *olo, uint64_t *ohi,
                        uint32_t *ocnt, uint64_t out_cap, uint64_t *n_out) {
-    HIPCHK(h, hipMemsetAsync(&h->ctl->cursor, 0, 8, h->stream));
+    { int rc0 = materialize(h); if (rc0) return rc0; }
+    HIPCHK(h, hipMemsetAsync(h->ctl->tally, 0, sizeof(h->ctl->tally) + 8, h->stream));   // tally[] + cursor
     const uint64_t waves = (h->cap + KDF_EXPORT_ROWS * 64 - 1) / (KDF_EXPORT_ROWS * 64);
     const unsigned blocks = (unsigned)((waves + 3) / 4);
     if (h->kw == 1) {
@@ -913,6 +952,7 @@ int kdf_scan_reads_dev(kdf_engine *h, const void *d_packed, const void *d_invali
     if (n_bases == 0) return KDF_OK;
     if (!d_packed || !d_invalid || !d_hit_bits) return fail(h, KDF_ERR_INVALID, "kdf_scan_reads_dev: NULL pointer");
     HIPCHK(h, hipSetDevice(h->device));
+    { int rc0 = materialize(h); if (rc0) return rc0; }
     const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
     launch_stream<MODE_SCAN>(h, (const uint64_t *)d_packed, (const uint64_t *)d_invalid, 0, n_tiles, (uint64_t *)d_hit_bits);
     HIPCHK(h, hipGetLastError());

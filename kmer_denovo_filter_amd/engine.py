@@ -108,7 +108,9 @@ class KmerEngine:
         return self
 
     def count_dev(self, d_packed: int, d_invalid: int, n_bases: int):
-        """Stream resident in HBM (raw device pointers, padded per stream_words)."""
+        """Stream resident in HBM (raw device pointers, padded per stream_words).
+        The engine launches on its own stream unless set_stream() was called:
+        the buffers must be complete (synchronise the producer) before the call."""
         self._ck(self._lib.kdf_count_reads_dev(self._h, c_void_p(d_packed), c_void_p(d_invalid), int(n_bases)))
         return self
 

@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
 def _dev_stream(n_reads, seed=20260417):
     import torch
     from kmer_denovo_filter_amd.synth import synth_stream
-    return synth_stream(n_reads, 150, 20_000_000, seed=seed, device="cuda:0")
+    ds = synth_stream(n_reads, 150, 20_000_000, seed=seed, device="cuda:0")
+    torch.cuda.synchronize()      # the engine launches on its own stream: the data must be complete
+    return ds
 
 
 def test_binned_vs_direct_vs_oracle_midsize(oracle):
