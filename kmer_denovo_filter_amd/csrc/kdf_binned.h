@@ -45,7 +45,8 @@ struct KbPlan {
 struct KbScratch {
     unsigned long long *hist1;      // [2^c1]
     unsigned long long *bin_start;  // [2^c1 + 1]
-    unsigned long long *cursor;     // [2^c1]
+    uint32_t *hist_wg;              // [n_wg][2^c1] per-workgroup coarse histogram
+    uint32_t *wg_base;              // [n_wg][2^c1] exclusive prefix of hist_wg over the workgroups
     unsigned long long *chunk_first;// [2^c1 + 1]
     unsigned long long *totals;     // [4]: n_entries, n_chunks, n_failed, claimed
     unsigned int *failed_flag;      // [1]: set when the scatter pass disagrees with the histogram pass
@@ -126,32 +127,58 @@ struct KbWindows {
     }
 };
 
+// A0: persistent workgroups.  Workgroup w owns slabs [w*spw, (w+1)*spw) in BOTH
+// passes; it accumulates its coarse-bin histogram in LDS over all its slabs and
+// writes ONE row hist_wg[w][bin] (no global atomics).
 template <int KW>
 __global__ __launch_bounds__(KB_THREADS) void kb_hist1_kernel(
     const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid, uint64_t n_tiles, int k,
-    KbPlan plan, KbScratch s)
+    KbPlan plan, KbScratch s, uint32_t slabs_per_wg)
 {
     __shared__ uint32_t hist[1 << KB_C1_MAX];
     constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT;      // threads per tile
-    for (int i = threadIdx.x; i < (1 << plan.c1); i += KB_THREADS) hist[i] = 0;
+    constexpr uint32_t TILES_PER_SLAB = KB_THREADS / TPT;
+    const int nb = 1 << plan.c1;
+    for (int i = threadIdx.x; i < nb; i += KB_THREADS) hist[i] = 0;
     __syncthreads();
-    const uint64_t tile = (uint64_t)blockIdx.x * (KB_THREADS / TPT) + threadIdx.x / TPT;
-    KbWindows<KW> win;
-    win.load(packed, invalid, tile, n_tiles, threadIdx.x % TPT, k);
-    if (win.valid) {
+    const uint64_t slab0 = (uint64_t)blockIdx.x * slabs_per_wg;
+    for (uint32_t sl = 0; sl < slabs_per_wg; ++sl) {
+        const uint64_t tile = (slab0 + sl) * TILES_PER_SLAB + threadIdx.x / TPT;
+        if ((slab0 + sl) * TILES_PER_SLAB >= n_tiles) break;
+        KbWindows<KW> win;
+        win.load(packed, invalid, tile, n_tiles, threadIdx.x % TPT, k);
+        if (win.valid) {
 #pragma unroll
-        for (int u = 0; u < WPT; ++u) {
-            if (!((win.valid >> u) & 1)) continue;
-            uint64_t lo, hi; win.key(u, lo, hi);
-            atomicAdd(&hist[kb_coarse(plan, kdf_hash(lo, hi))], 1u);
+            for (int u = 0; u < WPT; ++u) {
+                if (!((win.valid >> u) & 1)) continue;
+                uint64_t lo, hi; win.key(u, lo, hi);
+                atomicAdd(&hist[kb_coarse(plan, kdf_hash(lo, hi))], 1u);
+            }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < (1 << plan.c1); i += KB_THREADS)
-        if (hist[i]) atomicAdd(&s.hist1[i], (unsigned long long)hist[i]);
+    for (int i = threadIdx.x; i < nb; i += KB_THREADS) s.hist_wg[(uint64_t)blockIdx.x * nb + i] = hist[i];
 }
 
-// single workgroup: bin starts, cursors, chunk layout
+// column scan: block b = coarse bin b; exclusive prefix over the workgroups ->
+// wg_base[w][b] (offset of workgroup w inside bin b) and the bin total hist1[b]
+__global__ __launch_bounds__(256) void kb_colscan_kernel(KbPlan plan, KbScratch s, uint32_t n_wg) {
+    __shared__ uint32_t wsum[32];
+    const int nb = 1 << plan.c1;
+    const uint32_t b = blockIdx.x;
+    unsigned long long carry = 0;
+    for (uint32_t w0 = 0; w0 < n_wg; w0 += 256) {
+        const uint32_t w = w0 + threadIdx.x;
+        const uint32_t v = w < n_wg ? s.hist_wg[(uint64_t)w * nb + b] : 0;
+        uint32_t tot = 0;
+        const uint32_t ex = kb_block_exscan(v, wsum, &tot);
+        if (w < n_wg) s.wg_base[(uint64_t)w * nb + b] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) s.hist1[b] = carry;
+}
+
+// single workgroup: bin starts, chunk layout
 __global__ __launch_bounds__(KB_THREADS) void kb_scan1_kernel(KbPlan plan, KbScratch s, uint32_t chunk, KdfCtl *ctl) {
     __shared__ unsigned long long a[(1 << KB_C1_MAX) + 1], c[(1 << KB_C1_MAX) + 1];
     const int nb = 1 << plan.c1;
@@ -167,75 +194,89 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scan1_kernel(KbPlan plan, KbScr
         if (acc) atomicAdd(&ctl->windows[0], acc);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i <= nb; i += KB_THREADS) {
-        s.bin_start[i] = a[i]; s.chunk_first[i] = c[i];
-        if (i < nb) s.cursor[i] = a[i];
-    }
+    for (int i = threadIdx.x; i <= nb; i += KB_THREADS) { s.bin_start[i] = a[i]; s.chunk_first[i] = c[i]; }
 }
 
+// A1: same slab ownership as A0.  Each workgroup keeps a private cursor per bin
+// (bin_start + wg_base, advanced slab by slab): no global atomics, deterministic
+// layout.  Per slab: rank the windows with LDS atomics, counting-sort them into
+// an LDS image, then copy out run by run (a half-wave per bin) so that every
+// (workgroup, bin) run is one contiguous global write.
 template <int KW>
 __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
     const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid, uint64_t n_tiles, int k,
-    KbPlan plan, KbScratch s)
+    KbPlan plan, KbScratch s, uint32_t slabs_per_wg)
 {
     constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT, SLAB = KB_THREADS * WPT;
+    constexpr uint32_t TILES_PER_SLAB = KB_THREADS / TPT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t *slo = (uint64_t *)smem;                                   // [SLAB]
     uint64_t *shi = KW == 2 ? slo + SLAB : nullptr;                     // [SLAB] wide
-    uint32_t *hist = (uint32_t *)(smem + (size_t)SLAB * 8 * KW);        // [512]
+    unsigned long long *gcur = (unsigned long long *)(smem + (size_t)SLAB * 8 * KW);   // [512] next free entry of this WG per bin
+    unsigned long long *gend = gcur + (1 << KB_C1_MAX);                 // [512] end of this WG's range (guard)
+    uint32_t *hist = (uint32_t *)(gend + (1 << KB_C1_MAX));             // [512]
     uint32_t *offs = hist + (1 << KB_C1_MAX);                           // [512]
     uint32_t *wsum = offs + (1 << KB_C1_MAX);                           // [32]
-    unsigned long long *gbase = (unsigned long long *)(wsum + 32);      // [512]
     const int nb = 1 << plan.c1;
-    for (int i = threadIdx.x; i < nb; i += KB_THREADS) hist[i] = 0;
+    for (int i = threadIdx.x; i < nb; i += KB_THREADS) {
+        hist[i] = 0;
+        const unsigned long long st = s.bin_start[i] + s.wg_base[(uint64_t)blockIdx.x * nb + i];
+        gcur[i] = st;
+        gend[i] = st + s.hist_wg[(uint64_t)blockIdx.x * nb + i];
+    }
     __syncthreads();
-    const uint64_t tile = (uint64_t)blockIdx.x * (KB_THREADS / TPT) + threadIdx.x / TPT;
-    KbWindows<KW> win;
-    win.load(packed, invalid, tile, n_tiles, threadIdx.x % TPT, k);
-    uint64_t klo[WPT], khi[KW == 2 ? WPT : 1];
-    uint32_t br[WPT];                       // bin << 16 | rank  (rank < SLAB <= 16384)
-    if (win.valid) {
+    const uint64_t slab0 = (uint64_t)blockIdx.x * slabs_per_wg;
+    const int half = threadIdx.x >> 5, lane32 = threadIdx.x & 31;
+    constexpr int NHALF = KB_THREADS / 32;
+    for (uint32_t sl = 0; sl < slabs_per_wg; ++sl) {
+        if ((slab0 + sl) * TILES_PER_SLAB >= n_tiles) break;          // uniform
+        const uint64_t tile = (slab0 + sl) * TILES_PER_SLAB + threadIdx.x / TPT;
+        KbWindows<KW> win;
+        win.load(packed, invalid, tile, n_tiles, threadIdx.x % TPT, k);
+        uint64_t klo[WPT], khi[KW == 2 ? WPT : 1];
+        uint32_t br[WPT];                       // bin << 16 | rank  (rank < SLAB <= 16384)
+        if (win.valid) {
 #pragma unroll
-        for (int u = 0; u < WPT; ++u) {
-            if (!((win.valid >> u) & 1)) continue;
-            uint64_t lo, hi; win.key(u, lo, hi);
-            klo[u] = lo; if constexpr (KW == 2) khi[u] = hi;
-            const uint32_t bin = kb_coarse(plan, kdf_hash(lo, hi));
-            br[u] = (bin << 16) | atomicAdd(&hist[bin], 1u);
+            for (int u = 0; u < WPT; ++u) {
+                if (!((win.valid >> u) & 1)) continue;
+                uint64_t lo, hi; win.key(u, lo, hi);
+                klo[u] = lo; if constexpr (KW == 2) khi[u] = hi;
+                const uint32_t bin = kb_coarse(plan, kdf_hash(lo, hi));
+                br[u] = (bin << 16) | atomicAdd(&hist[bin], 1u);
+            }
         }
-    }
-    __syncthreads();
-    uint32_t total = 0;
-    {
-        const uint32_t v = threadIdx.x < nb ? hist[threadIdx.x] : 0;
-        const uint32_t ex = kb_block_exscan(v, wsum, &total);
-        if (threadIdx.x < nb) {
-            offs[threadIdx.x] = ex;
-            unsigned long long g = v ? atomicAdd(&s.cursor[threadIdx.x], (unsigned long long)v) : 0ull;
-            // guard: the histogram pass sized this bin; if the stream changed
-            // between the two passes (caller error) refuse to write past it
-            if (v && g + v > s.bin_start[threadIdx.x + 1]) { g = ~0ull; atomicOr(&s.failed_flag[0], 1u); }
-            gbase[threadIdx.x] = g;
+        __syncthreads();
+        {
+            const uint32_t v = threadIdx.x < nb ? hist[threadIdx.x] : 0;
+            const uint32_t ex = kb_block_exscan(v, wsum, nullptr);
+            if (threadIdx.x < nb) offs[threadIdx.x] = ex;
         }
-    }
-    __syncthreads();
-    if (win.valid) {
+        __syncthreads();
+        if (win.valid) {
 #pragma unroll
-        for (int u = 0; u < WPT; ++u) {
-            if (!((win.valid >> u) & 1)) continue;
-            const uint32_t pos = offs[br[u] >> 16] + (br[u] & 0xFFFF);
-            slo[pos] = klo[u];
-            if constexpr (KW == 2) shi[pos] = khi[u];
+            for (int u = 0; u < WPT; ++u) {
+                if (!((win.valid >> u) & 1)) continue;
+                const uint32_t pos = offs[br[u] >> 16] + (br[u] & 0xFFFF);
+                slo[pos] = klo[u];
+                if constexpr (KW == 2) shi[pos] = khi[u];
+            }
         }
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < total; i += KB_THREADS) {
-        const uint64_t lo = slo[i], hi = KW == 2 ? shi[i] : 0;
-        const uint32_t bin = kb_coarse(plan, kdf_hash(lo, hi));
-        if (gbase[bin] == ~0ull) continue;
-        const unsigned long long dst = gbase[bin] + (i - offs[bin]);
-        s.ent_lo[dst] = lo;
-        if constexpr (KW == 2) s.ent_hi[dst] = hi;
+        __syncthreads();
+        for (int bin = half; bin < nb; bin += NHALF) {
+            const uint32_t n = hist[bin], o = offs[bin];
+            const unsigned long long g = gcur[bin];
+            if (g + n > gend[bin]) {           // the stream changed between the passes: never write past the range
+                if (lane32 == 0 && n) s.failed_flag[0] = 1;
+                continue;
+            }
+            for (uint32_t i = lane32; i < n; i += 32) {
+                s.ent_lo[g + i] = slo[o + i];
+                if constexpr (KW == 2) s.ent_hi[g + i] = shi[o + i];
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb; i += KB_THREADS) { gcur[i] += hist[i]; hist[i] = 0; }
+        __syncthreads();
     }
 }
 
@@ -394,6 +435,8 @@ __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
         __syncthreads();
         const uint32_t nruns = (uint32_t)((j1 - jb) < (unsigned long long)KB_C_RUNS ? (j1 - jb) : (unsigned long long)KB_C_RUNS);
         constexpr int EPB = 16;    // entries per thread per batch: EPB loads in flight per lane
+        // (ei * inv_total) >> 32 ~= ei * nruns / total
+        const unsigned long long inv_total = total ? (((unsigned long long)nruns << 32) / total) : 0;
         for (uint32_t e0 = 0; e0 < total; e0 += KB_C_THREADS * EPB) {   // wave-uniform trip count
           uint64_t bklo[EPB], bkhi[KW == 2 ? EPB : 1];
 #pragma unroll
@@ -401,10 +444,12 @@ __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
             const uint32_t ei = e0 + q * KB_C_THREADS + threadIdx.x;
             bklo[q] = 0; if constexpr (KW == 2) bkhi[q] = 0;
             if (ei < total) {
-                // largest r with run_pref[r] <= ei (prefixes are non-decreasing, so
-                // among equal prefixes the last -- the non-empty run -- wins)
-                uint32_t lo_ = 0, hi_ = nruns;
-                while (hi_ - lo_ > 1) { const uint32_t mid = (lo_ + hi_) >> 1; if (run_pref[mid] <= ei) lo_ = mid; else hi_ = mid; }
+                // largest r with run_pref[r] <= ei.  Runs of a bucket have nearly equal
+                // lengths (hash-uniform), so interpolate and correct by a step or two.
+                uint32_t lo_ = (uint32_t)(((unsigned long long)ei * inv_total) >> 32);
+                if (lo_ >= nruns) lo_ = nruns - 1;
+                while (run_pref[lo_] > ei) --lo_;
+                while (lo_ + 1 < nruns && run_pref[lo_ + 1] <= ei) ++lo_;
                 const unsigned long long src = run_first[lo_] + (ei - run_pref[lo_]);
                 bklo[q] = s.ent_lo[src];
                 if constexpr (KW == 2) bkhi[q] = s.ent_hi[src];

@@ -11,16 +11,21 @@
 #define KDF_SHARDS  64                      // sharded statistics counters
 
 // ---------------------------------------------------------------------------
-// hash: 64-bit bijective mixer (xor-shift / odd multiply), so narrow keys can
-// be recovered from (bucket, remainder) if a later layout wants to.
+// hash: fold the high half into the low half, then ONE 64-bit multiply by an odd
+// constant (Fibonacci hashing).  Only the TOP bits of the result are ever used
+// (bucket = top bits, home slot = the bits below), and those depend on every
+// input bit.  A 64-bit multiply is ~8 quarter-rate VALU instructions on CDNA4
+// and the hash is evaluated several times per k-mer along the binned pipeline,
+// so a second multiply is not free.  Bijective on 64 bits (xor-shift and odd
+// multiply are both invertible).
 __host__ __device__ __forceinline__ uint64_t kdf_mix64(uint64_t x) {
-    x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
-    x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
     x ^= x >> 32;
+    x *= 0x9E3779B97F4A7C15ull;
     return x;
 }
 __host__ __device__ __forceinline__ uint64_t kdf_hash(uint64_t lo, uint64_t hi) {
-    return kdf_mix64(lo ^ (hi * 0x9E3779B97F4A7C15ull));
+    // wide keys: rotate hi so that its used (low) bits land on lo's upper half
+    return kdf_mix64(lo ^ ((hi << 37) | (hi >> 27)));
 }
 
 // reverse the 32 two-bit groups of a 64-bit word

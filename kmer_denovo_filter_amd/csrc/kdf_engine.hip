@@ -244,8 +244,8 @@ struct kdf_engine {
     // binned (LDS-bucket) path: scratch + options
     unsigned long long *kb_small = nullptr;   // hist1 | bin_start | cursor | chunk_first | totals
     unsigned long long *kb_totals_host = nullptr;   // pinned [4]
-    void *kb_buf[4] = {nullptr, nullptr, nullptr, nullptr};   // ent_lo, ent_hi, chunk_off, failed
-    size_t kb_bytes[4] = {0, 0, 0, 0};
+    void *kb_buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ent_lo, ent_hi, chunk_off, failed, hist_wg, wg_base
+    size_t kb_bytes[6] = {0, 0, 0, 0, 0, 0};
     uint64_t opt_binned_min_positions = 1ull << 22;  // smaller batches use the direct global-table kernels
     uint32_t opt_binned_filtered_min_log2cap = 26;   // count --if goes binned only for tables this large
     int opt_force_path = 0;                          // 0 auto, 1 direct, 2 binned
@@ -466,21 +466,29 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
         HIPCHK(h, hipHostMalloc((void **)&h->kb_totals_host, 128));
     }
     KbScratch s{};
-    s.hist1 = h->kb_small; s.bin_start = s.hist1 + (nb1 + 1); s.cursor = s.bin_start + (nb1 + 1);
-    s.chunk_first = s.cursor + (nb1 + 1); s.totals = s.chunk_first + (nb1 + 1);
+    s.hist1 = h->kb_small; s.bin_start = s.hist1 + (nb1 + 1);
+    s.chunk_first = s.bin_start + 2 * (nb1 + 1); s.totals = s.chunk_first + (nb1 + 1);
     s.failed_flag = (unsigned int *)(s.totals + 8);
-    const size_t lds_a1 = (size_t)SLAB * 8 * KW + (size_t)(2 * nb1 + 32) * 4 + (size_t)nb1 * 8;
     const size_t lds_b = (size_t)CHUNK * 8 * KW + (size_t)(2 * KB_F + 32) * 4 + 16;
     const size_t lds_c = ((size_t)8 * KW + 4) * ((size_t)1 << plan.bucket_bits) + (2 + 32 + KB_C_RUNS) * 4 + (size_t)KB_C_RUNS * 8;
+    const size_t lds_a1 = (size_t)SLAB * 8 * KW + (size_t)nb1 * 16 + (size_t)(2 * nb1 + 32) * 4;
     int rc = kb_set_lds_attrs<KW>(h, lds_a1, lds_b, lds_c);
     if (rc) return rc;
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, h->stream); }
 
-    const unsigned grid_a = (unsigned)((n_tiles + (KB_THREADS / TPT) - 1) / (KB_THREADS / TPT));
-    HIPCHK(h, hipMemsetAsync(s.hist1, 0, (size_t)(nb1 + 1) * 8, h->stream));
-    hipLaunchKernelGGL(kb_hist1_kernel<KW>, dim3(grid_a), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s);
+    // persistent A0/A1 workgroups: each owns slabs_per_wg consecutive slabs
+    const uint64_t n_slabs = (n_tiles + (KB_THREADS / TPT) - 1) / (KB_THREADS / TPT);
+    const uint32_t n_wg = (uint32_t)std::min<uint64_t>(n_slabs, 4096);
+    const uint32_t slabs_per_wg = (uint32_t)((n_slabs + n_wg - 1) / n_wg);
+    const unsigned grid_a = (unsigned)((n_slabs + slabs_per_wg - 1) / slabs_per_wg);
+    const int nbins = 1 << plan.c1;
+    if ((rc = kb_reserve(h, 4, (size_t)grid_a * nbins * 4))) return rc;
+    if ((rc = kb_reserve(h, 5, (size_t)grid_a * nbins * 4))) return rc;
+    s.hist_wg = (uint32_t *)h->kb_buf[4]; s.wg_base = (uint32_t *)h->kb_buf[5];
+    hipLaunchKernelGGL(kb_hist1_kernel<KW>, dim3(grid_a), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
+    hipLaunchKernelGGL(kb_colscan_kernel, dim3(nbins), dim3(256), 0, h->stream, plan, s, (uint32_t)grid_a);
     hipLaunchKernelGGL(kb_scan1_kernel, dim3(1), dim3(KB_THREADS), 0, h->stream, plan, s, (uint32_t)CHUNK, h->ctl);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(h->kb_totals_host, s.totals, 32, hipMemcpyDeviceToHost, h->stream));
@@ -498,7 +506,7 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     s.chunk_off = (uint32_t *)h->kb_buf[2]; s.failed = (uint32_t *)h->kb_buf[3];
     HIPCHK(h, hipMemsetAsync(s.failed, 0, failed_bytes, h->stream));
 
-    hipLaunchKernelGGL(kb_scatter1_kernel<KW>, dim3(grid_a), dim3(KB_THREADS), lds_a1, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s);
+    hipLaunchKernelGGL(kb_scatter1_kernel<KW>, dim3(grid_a), dim3(KB_THREADS), lds_a1, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
     hipLaunchKernelGGL(kb_finesort_kernel<KW>, dim3((unsigned)n_chunks), dim3(KB_THREADS), lds_b, h->stream, plan, s);
     if (filtered && (rc = materialize(h))) return rc;
     const int nonempty = h->lazy_empty ? 0 : 1;   // 0: kernel C rewrites every bucket (this IS the clear)
@@ -670,7 +678,7 @@ void kdf_destroy(kdf_engine *h) {
     table_free(h->t);
     prof_collect(h);
     for (int i = 0; i < 4; ++i) if (h->stage[i]) (void)hipFree(h->stage[i]);
-    for (int i = 0; i < 4; ++i) if (h->kb_buf[i]) (void)hipFree(h->kb_buf[i]);
+    for (int i = 0; i < 6; ++i) if (h->kb_buf[i]) (void)hipFree(h->kb_buf[i]);
     if (h->kb_small) (void)hipFree(h->kb_small);
     if (h->kb_totals_host) (void)hipHostFree(h->kb_totals_host);
     if (h->ctl) (void)hipFree(h->ctl);
