@@ -39,6 +39,7 @@ struct KbPlan {
     uint32_t c2;            // fine bits (<= KB_F_BITS)
     uint32_t sub_bits;      // table buckets per partition bucket = 2^sub_bits
     uint32_t log2cap, bucket_bits;
+    uint32_t dbg;           // experiments only: 1 skip LDS insert, 2 skip gather loads, 4 skip write-back
 };
 
 // device scratch shared by the kernels of one pass
@@ -379,8 +380,8 @@ __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
     uint32_t *tcnt = (uint32_t *)(smem + (size_t)B * 8 * KW); // [B]
     uint32_t &sh_failed = tcnt[B], &sh_claimed = tcnt[B + 1];
     uint32_t *wsum = tcnt + B + 2;                            // [32]
-    uint32_t *run_pref = wsum + 32;                           // [KB_C_RUNS] exclusive prefix of run lengths
-    unsigned long long *run_first = (unsigned long long *)(run_pref + KB_C_RUNS);   // [KB_C_RUNS] (B + 34 + KB_C_RUNS is even: 8-aligned)
+    uint32_t *run_len = wsum + 32;                            // [KB_C_RUNS] entries of this bucket in each chunk
+    unsigned long long *run_first = (unsigned long long *)(run_len + KB_C_RUNS);   // [KB_C_RUNS] (B + 34 + KB_C_RUNS is even: 8-aligned)
 
     // `plan` describes the table the partition was built for.  In MODE_REPLAY
     // that is the OLD geometry (the host has grown the table since) and `t` is
@@ -429,99 +430,116 @@ __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
                 first = bstart + (j - j0) * (unsigned long long)CHUNK + r0;
             }
         }
-        uint32_t total = 0;
-        const uint32_t ex = kb_block_exscan(len, wsum, &total);
-        if (threadIdx.x < KB_C_RUNS) { run_pref[threadIdx.x] = ex; run_first[threadIdx.x] = first; }
+        if (threadIdx.x < KB_C_RUNS) { run_len[threadIdx.x] = len; run_first[threadIdx.x] = first; }
         __syncthreads();
         const uint32_t nruns = (uint32_t)((j1 - jb) < (unsigned long long)KB_C_RUNS ? (j1 - jb) : (unsigned long long)KB_C_RUNS);
-        constexpr int EPB = 16;    // entries per thread per batch: EPB loads in flight per lane
-        // (ei * inv_total) >> 32 ~= ei * nruns / total
-        const unsigned long long inv_total = total ? (((unsigned long long)nruns << 32) / total) : 0;
-        for (uint32_t e0 = 0; e0 < total; e0 += KB_C_THREADS * EPB) {   // wave-uniform trip count
-          uint64_t bklo[EPB], bkhi[KW == 2 ? EPB : 1];
+        // A wave owns whole runs, RPW at a time: their first 64 entries are loaded
+        // together (RPW loads in flight per lane), then inserted.  Runs average
+        // ~CHUNK / 2^c2 = 64 entries, so most need no tail pass.  No per-entry
+        // search, and all loops here are wave-uniform.
+        constexpr int RPW = 8;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        constexpr int NWAVES = KB_C_THREADS / 64;
+        for (uint32_t rb = wave * RPW; rb < nruns; rb += NWAVES * RPW) {
+            uint64_t bklo[RPW], bkhi[KW == 2 ? RPW : 1];
+            uint32_t bln[RPW];
 #pragma unroll
-          for (int q = 0; q < EPB; ++q) {
-            const uint32_t ei = e0 + q * KB_C_THREADS + threadIdx.x;
-            bklo[q] = 0; if constexpr (KW == 2) bkhi[q] = 0;
-            if (ei < total) {
-                // largest r with run_pref[r] <= ei.  Runs of a bucket have nearly equal
-                // lengths (hash-uniform), so interpolate and correct by a step or two.
-                uint32_t lo_ = (uint32_t)(((unsigned long long)ei * inv_total) >> 32);
-                if (lo_ >= nruns) lo_ = nruns - 1;
-                while (run_pref[lo_] > ei) --lo_;
-                while (lo_ + 1 < nruns && run_pref[lo_ + 1] <= ei) ++lo_;
-                const unsigned long long src = run_first[lo_] + (ei - run_pref[lo_]);
-                bklo[q] = s.ent_lo[src];
-                if constexpr (KW == 2) bkhi[q] = s.ent_hi[src];
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < EPB; ++q) {
-            const uint32_t ei = e0 + q * KB_C_THREADS + threadIdx.x;
-            bool todo = ei < total;
-            const uint64_t klo = bklo[q], khi = KW == 2 ? bkhi[q] : 0;
-            const uint64_t h = kdf_hash(klo, khi);
-            const uint64_t home = h >> (64 - plan.log2cap);
-            if (plan.sub_bits && (home >> plan.bucket_bits) != bucket) todo = false;   // sibling bucket's entry
-            if constexpr (MODE == KB_MODE_REPLAY) {
-                const uint64_t slot = kdf_home(t, h);
-                bool ok = true;
-                if constexpr (KW == 1) { if (todo) ok = kdf_add_narrow<true>(t, klo, 1u, slot, t.lo[slot], claimed); }
-                else ok = kdf_add_wide<true>(t, todo, klo, khi, 1u, slot, claimed);
-                if (!ok) failed = true;
-                continue;
-            }
-            if constexpr (KW == 1) {
-                if (!todo) continue;
-                uint32_t sl = (uint32_t)home & bmask;
-                for (uint32_t n = 0;; ++n) {
-                    if (n > bmask) { failed = true; break; }
-                    uint64_t cur = tlo[sl];
-                    if (cur == KDF_EMPTY && MODE == KB_MODE_INSERT) {
-                        cur = atomicCAS((unsigned long long *)&tlo[sl], KDF_EMPTY, klo);
-                        if (cur == KDF_EMPTY) { claimed++; cur = klo; }
-                    }
-                    if (cur == klo) { kb_lds_sat_add(&tcnt[sl], 1u); break; }
-                    if (cur == KDF_EMPTY) break;                         // FILTERED: absent
-                    sl = (sl + 1) & bmask;
+            for (int q = 0; q < RPW; ++q) {
+                const uint32_t r = rb + q;
+                bln[q] = r < nruns ? run_len[r] : 0;
+                bklo[q] = 0; if constexpr (KW == 2) bkhi[q] = 0;
+                if ((uint32_t)lane < bln[q]) {
+                    const unsigned long long src = run_first[r] + lane;
+                    if (plan.dbg & 2) bklo[q] = (src * 0x9E3779B97F4A7C15ull) >> 2;
+                    else bklo[q] = s.ent_lo[src];
+                    if constexpr (KW == 2) bkhi[q] = s.ent_hi[src];
                 }
-            } else {
-                // wide: claim hi with PENDING, publish lo, then the final hi (all in LDS).
-                // No lane waits inside a divergent loop (kdf_device.h): a lane that meets
-                // a PENDING slot retries in the next pass of this wave-uniform loop.
-                while (__any(todo)) {
+            }
+            // pass 0: the RPW prefetched heads; pass 1..: tails of runs longer than 64 (rare)
+            uint32_t maxlen = 0;
+#pragma unroll
+            for (int q = 0; q < RPW; ++q) maxlen = bln[q] > maxlen ? bln[q] : maxlen;
+            for (uint32_t base_i = 0; base_i < maxlen; base_i += 64) {
+#pragma unroll
+              for (int q = 0; q < RPW; ++q) {
+                if (base_i >= bln[q]) continue;                         // wave-uniform
+                const uint32_t i = base_i + lane;
+                bool todo = i < bln[q];
+                uint64_t klo = bklo[q], khi = KW == 2 ? bkhi[q] : 0;
+                if (base_i) {                                           // tail: load now
+                    klo = 0; khi = 0;
                     if (todo) {
-                        uint32_t sl = (uint32_t)home & bmask;
-                        int res = -1;                                    // -1 probing, 0 done, 1 full, 2 blocked
-                        for (uint32_t n = 0; res < 0; ++n) {
-                            if (n > bmask) { res = 1; break; }
-                            uint64_t chi = __hip_atomic_load(&thi[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (chi == KDF_EMPTY && MODE == KB_MODE_INSERT) {
-                                chi = atomicCAS((unsigned long long *)&thi[sl], KDF_EMPTY, khi | KDF_PENDING);
-                                if (chi == KDF_EMPTY) {
-                                    __hip_atomic_store(&tlo[sl], klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    __hip_atomic_store(&thi[sl], khi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    claimed++;
-                                    kb_lds_sat_add(&tcnt[sl], 1u);
-                                    res = 0; break;
-                                }
-                            }
-                            if (chi == KDF_EMPTY) { res = 0; break; }    // FILTERED: absent
-                            if ((chi & ~KDF_PENDING) == khi) {
-                                if (chi & KDF_PENDING) { res = 2; break; }
-                                const uint64_t clo = __hip_atomic_load(&tlo[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                if (clo == klo) { kb_lds_sat_add(&tcnt[sl], 1u); res = 0; break; }
-                            }
-                            sl = (sl + 1) & bmask;
-                        }
-                        if (res != 2) { todo = false; if (res == 1) failed = true; }
+                        const unsigned long long src = run_first[rb + q] + i;
+                        klo = s.ent_lo[src];
+                        if constexpr (KW == 2) khi = s.ent_hi[src];
                     }
-                    __builtin_amdgcn_wave_barrier();
                 }
+                const uint64_t h = kdf_hash(klo, khi);
+                const uint64_t home = h >> (64 - plan.log2cap);
+                if (plan.sub_bits && (home >> plan.bucket_bits) != bucket) todo = false;   // sibling bucket's entry
+                if constexpr (MODE == KB_MODE_REPLAY) {
+                    const uint64_t slot = kdf_home(t, h);
+                    bool ok = true;
+                    if constexpr (KW == 1) { if (todo) ok = kdf_add_narrow<true>(t, klo, 1u, slot, t.lo[slot], claimed); }
+                    else ok = kdf_add_wide<true>(t, todo, klo, khi, 1u, slot, claimed);
+                    if (!ok) failed = true;
+                    continue;
+                }
+                if constexpr (KW == 1) {
+                    if (!todo) continue;
+                    if (plan.dbg & 1) { claimed += (uint32_t)(klo >> 61); continue; }
+                    uint32_t sl = (uint32_t)home & bmask;
+                    uint64_t cur = tlo[sl];
+                    if (cur == klo) { atomicAdd(&tcnt[sl], 1u); continue; }      // common case: first probe hits
+                    for (uint32_t n = 0;; ++n) {
+                        if (n > bmask) { failed = true; break; }
+                        if (cur == KDF_EMPTY && MODE == KB_MODE_INSERT) {
+                            cur = atomicCAS((unsigned long long *)&tlo[sl], KDF_EMPTY, klo);
+                            if (cur == KDF_EMPTY) { claimed++; cur = klo; }
+                        }
+                        if (cur == klo) { atomicAdd(&tcnt[sl], 1u); break; }
+                        if (cur == KDF_EMPTY) break;                         // FILTERED: absent
+                        sl = (sl + 1) & bmask;
+                        cur = tlo[sl];
+                    }
+                } else {
+                    // wide: claim hi with PENDING, publish lo, then the final hi (all in LDS).
+                    // No lane waits inside a divergent loop (kdf_device.h): a lane that meets
+                    // a PENDING slot retries in the next pass of this wave-uniform loop.
+                    while (__any(todo)) {
+                        if (todo) {
+                            uint32_t sl = (uint32_t)home & bmask;
+                            int res = -1;                                    // -1 probing, 0 done, 1 full, 2 blocked
+                            for (uint32_t n = 0; res < 0; ++n) {
+                                if (n > bmask) { res = 1; break; }
+                                uint64_t chi = __hip_atomic_load(&thi[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (chi == KDF_EMPTY && MODE == KB_MODE_INSERT) {
+                                    chi = atomicCAS((unsigned long long *)&thi[sl], KDF_EMPTY, khi | KDF_PENDING);
+                                    if (chi == KDF_EMPTY) {
+                                        __hip_atomic_store(&tlo[sl], klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        __hip_atomic_store(&thi[sl], khi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        claimed++;
+                                        atomicAdd(&tcnt[sl], 1u);
+                                        res = 0; break;
+                                    }
+                                }
+                                if (chi == KDF_EMPTY) { res = 0; break; }    // FILTERED: absent
+                                if ((chi & ~KDF_PENDING) == khi) {
+                                    if (chi & KDF_PENDING) { res = 2; break; }
+                                    const uint64_t clo = __hip_atomic_load(&tlo[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    if (clo == klo) { atomicAdd(&tcnt[sl], 1u); res = 0; break; }
+                                }
+                                sl = (sl + 1) & bmask;
+                            }
+                            if (res != 2) { todo = false; if (res == 1) failed = true; }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+              }
             }
-          }
         }
-        __syncthreads();       // run_pref / run_first are rewritten by the next round
+        __syncthreads();       // run_len / run_first are rewritten by the next round
     }
     if (failed) atomicOr(&sh_failed, 1u);
     if (claimed) atomicAdd(&sh_claimed, claimed);
@@ -549,12 +567,18 @@ __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
         }
         return;
     }
+    if (plan.dbg & 4) return;
+    // LDS counts were advanced with plain (wrapping, non-returning) adds.  A pass
+    // adds fewer than 2^32 to a slot, so a slot wrapped iff its new value is below
+    // the value it had in HBM: saturate those (Jellyfish's 4-byte counter).
     for (uint32_t i = threadIdx.x; i < B; i += KB_C_THREADS) {
         if constexpr (MODE == KB_MODE_INSERT) {
             t.lo[slot0 + i] = tlo[i];
             if constexpr (KW == 2) t.hi[slot0 + i] = thi[i];
         }
-        t.cnt[slot0 + i] = tcnt[i];
+        uint32_t c = tcnt[i];
+        if (table_nonempty && c < t.cnt[slot0 + i]) c = 0xFFFFFFFFu;
+        t.cnt[slot0 + i] = c;
     }
     if (threadIdx.x == 0 && sh_claimed)
         atomicAdd(&ctl->distinct[(bucket % KDF_SHARDS) * 16], (unsigned long long)sh_claimed);

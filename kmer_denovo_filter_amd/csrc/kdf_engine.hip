@@ -249,6 +249,7 @@ struct kdf_engine {
     uint64_t opt_binned_min_positions = 1ull << 22;  // smaller batches use the direct global-table kernels
     uint32_t opt_binned_filtered_min_log2cap = 26;   // count --if goes binned only for tables this large
     int opt_force_path = 0;                          // 0 auto, 1 direct, 2 binned
+    uint32_t opt_debug_flags = 0;                    // experiments only (KbPlan::dbg)
     uint64_t stat_binned_passes = 0, stat_replayed_buckets = 0;
     // optional HIP-event timing of the dominant (stream) kernel
     bool prof = false;
@@ -459,7 +460,8 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT, CHUNK = KbCfg<KW>::CHUNK, SLAB = KB_THREADS * WPT;
     const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
     if (n_tiles == 0) return KDF_OK;
-    const KbPlan plan = kb_make_plan(h->t);
+    KbPlan plan = kb_make_plan(h->t);
+    plan.dbg = h->opt_debug_flags;
     const int nb1 = 1 << KB_C1_MAX;
     if (!h->kb_small) {
         HIPCHK(h, hipMalloc((void **)&h->kb_small, (size_t)(4 * (nb1 + 1) + 16) * 8));
@@ -1050,6 +1052,7 @@ int kdf_set_option(kdf_engine *h, const char *name, int64_t value) {
     if (n == "binned_min_positions") h->opt_binned_min_positions = (uint64_t)value;
     else if (n == "binned_filtered_min_log2cap") h->opt_binned_filtered_min_log2cap = (uint32_t)value;
     else if (n == "force_path") h->opt_force_path = (int)value;
+    else if (n == "debug_flags") h->opt_debug_flags = (uint32_t)value;
     else return fail(h, KDF_ERR_INVALID, "kdf_set_option: unknown option %s", name);
     return KDF_OK;
 }
