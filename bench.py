@@ -82,15 +82,18 @@ def main():
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     merger = None
     if world > 1:
-        from kmer_denovo_filter_amd.distributed import OwnerPartitionedCount
-        merger = OwnerPartitionedCount(eng, dist.group.WORLD, dev)
+        from kmer_denovo_filter_amd.distributed import EngineOps, OwnerPartitionedCount
+        owner_eng = KmerEngine(k, capacity_hint=cap_hint, device=local_rank)     # keys this rank owns
+        owner_eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        merger = OwnerPartitionedCount(EngineOps(eng, dev), dist.group.WORLD, dev,
+                                       owner_ops=EngineOps(owner_eng, dev))
 
     def step():
         eng.clear()
         if merger is None:
             eng.count_dev(ds.packed.data_ptr(), ds.invalid.data_ptr(), ds.n_bases)
             return eng.count_ge(3)
-        return merger.count_and_merge(ds.packed.data_ptr(), ds.invalid.data_ptr(), ds.n_bases, min_count=3)
+        return merger.count_and_merge(ds.packed, ds.invalid, ds.n_bases, min_count=3)
 
     def barrier():
         if world > 1:
@@ -108,6 +111,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     kernel_ms, launches, positions = eng.profile_read()
+    stage_ms, stage_passes = eng.profile_stages()
+    binned_passes = eng.get_stat("binned_passes")
     eng.profile(False)
 
     if world > 1:
@@ -126,11 +131,26 @@ def main():
         return
 
     value = total_windows * args.steps / dt / 1e9
-    # dominant kernel: the stream (extract + hash + insert) kernel, per launch
+    # The count is one pipeline of four kernels per pass (binned path) or one
+    # kernel per chunk (direct path).  The roofline is taken over the whole pass:
+    # algorithmic bytes of the pass / summed duration of its kernels, HIP events
+    # on the launch stream (kdf_profile*).  rocprofv3's per-kernel averages of
+    # the same command (profiles/) add up to the same number.
     win_per_pos = windows / ds.n_bases
     alg_bytes_per_launch = (positions / max(launches, 1)) * win_per_pos * b_alg(k, L)
     avg_ms = kernel_ms / max(launches, 1)
     achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    binned = stage_passes > 0
+    stage_names = ["kb_hist1_kernel(+scans)", "kb_scatter1_kernel", "kb_finesort_kernel", "kb_bucket_kernel"]
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if binned and os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("reads_per_gpu") == args.reads and tj.get("k") == k and tj.get("read_len") == L:
+                traffic = tj.get("hbm_bytes_per_pass")
+        except Exception:  # noqa: BLE001
+            traffic = None
     out = {
         "metric": "canonical k-mers counted+filtered /sec (Gk-mer/s); % HBM roofline @ k=31",
         "value": round(value, 4),
@@ -153,15 +173,18 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "kdf_stream_kernel<insert>",
+            "kernel": ("binned count pass = " + " + ".join(stage_names)) if binned else "kdf_stream_kernel<insert>",
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK / 1e9,
             "unit": "GB/s",
             "frac": round(achieved * 1e9 / HBM_PEAK, 5),
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_note": "HBM bytes per pass from rocprofv3 TCC counters (profiles/traffic_latest.json, "
+                            "scripts/collect_traffic.sh); null when that file does not match this workload",
             "alg_bytes_per_window": b_alg(k, L),
             "launches": launches,
             "avg_launch_ms": round(avg_ms, 4),
+            "stage_avg_ms": {n: round(m / stage_passes, 4) for n, m in zip(stage_names, stage_ms)} if binned else None,
         },
     }
 

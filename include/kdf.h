@@ -91,6 +91,9 @@ int kdf_get_stat(kdf_engine *h, const char *name, int64_t *value);
  * launches and the stream positions they covered since kdf_profile(h, 1). */
 int kdf_profile(kdf_engine *h, int enable);
 int kdf_profile_read(kdf_engine *h, double *kernel_ms, uint64_t *launches, uint64_t *positions);
+/* Binned passes only: summed milliseconds of the four stages (A0 histogram +
+ * scans, A1 scatter, B fine sort, C bucket kernel) and the number of passes. */
+int kdf_profile_stages(kdf_engine *h, double *stage_ms4, uint64_t *passes);
 
 /* ------------------------------------------------- count (insert) stage -- */
 
@@ -154,6 +157,14 @@ int kdf_count_ge(kdf_engine *h, uint32_t min_count, uint64_t *n_out);
 int kdf_export_ge(kdf_engine *h, uint32_t min_count, uint64_t *keys_lo_out,
                   uint64_t *keys_hi_out, uint32_t *counts_out, uint64_t cap,
                   uint64_t *n_out);
+
+/* Device-to-device dump: the entries go to caller-owned HBM buffers (e.g. torch
+ * tensors that are then exchanged over RCCL); unsorted unless sorted != 0.
+ * d_keys_hi_out may be NULL for k <= 32, d_counts_out may be NULL when
+ * sorted == 0.  Synchronises the engine's stream before returning. */
+int kdf_export_ge_dev(kdf_engine *h, uint32_t min_count, void *d_keys_lo_out,
+                      void *d_keys_hi_out, void *d_counts_out, uint64_t cap,
+                      int sorted, uint64_t *n_out);
 
 /* ------------------------------------------------------ Module-3 scan ---- */
 

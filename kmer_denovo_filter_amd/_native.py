@@ -31,6 +31,7 @@ SYMBOLS = [
     ("kdf_get_stat", c_int, [_P, c_char_p, POINTER(c_int64)]),
     ("kdf_profile", c_int, [_P, c_int]),
     ("kdf_profile_read", c_int, [_P, POINTER(ctypes.c_double), POINTER(c_uint64), POINTER(c_uint64)]),
+    ("kdf_profile_stages", c_int, [_P, POINTER(ctypes.c_double), POINTER(c_uint64)]),
     ("kdf_count_reads", c_int, [_P, _P, _P, c_uint64]),
     ("kdf_count_reads_dev", c_int, [_P, _P, _P, c_uint64]),
     ("kdf_add_pairs", c_int, [_P, _P, _P, _P, c_uint64]),
@@ -42,6 +43,7 @@ SYMBOLS = [
     ("kdf_query_dev", c_int, [_P, _P, _P, c_uint64, _P]),
     ("kdf_count_ge", c_int, [_P, c_uint32, POINTER(c_uint64)]),
     ("kdf_export_ge", c_int, [_P, c_uint32, _P, _P, _P, c_uint64, POINTER(c_uint64)]),
+    ("kdf_export_ge_dev", c_int, [_P, c_uint32, _P, _P, _P, c_uint64, c_int, POINTER(c_uint64)]),
     ("kdf_scan_reads", c_int, [_P, _P, _P, c_uint64, _P, c_int64, _P, _P]),
     ("kdf_scan_reads_dev", c_int, [_P, _P, _P, c_uint64, _P]),
     ("kdf_stream_words", None, [c_uint64, POINTER(c_uint64), POINTER(c_uint64)]),

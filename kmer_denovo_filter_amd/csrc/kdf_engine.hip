@@ -257,6 +257,10 @@ struct kdf_engine {
     std::vector<uint64_t> prof_tiles;
     double prof_ms = 0.0;
     uint64_t prof_launches = 0, prof_positions = 0;
+    // binned pass: events around each stage (A0 hist, A1 scatter, B finesort, C bucket)
+    std::vector<std::vector<hipEvent_t>> prof_stage_ev;
+    double prof_stage_ms[4] = {0, 0, 0, 0};
+    uint64_t prof_stage_passes = 0;
     std::string err;
 };
 
@@ -418,6 +422,16 @@ static void prof_collect(kdf_engine *h) {
         (void)hipEventDestroy(h->prof_ev[i].first); (void)hipEventDestroy(h->prof_ev[i].second);
     }
     h->prof_ev.clear(); h->prof_tiles.clear();
+    for (auto &ev : h->prof_stage_ev) {
+        if (ev.size() == 5) {
+            (void)hipEventSynchronize(ev[4]);
+            bool ok = true; float ms[4];
+            for (int i = 0; i < 4; ++i) ok = ok && hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]) == hipSuccess;
+            if (ok) { for (int i = 0; i < 4; ++i) h->prof_stage_ms[i] += ms[i]; h->prof_stage_passes++; }
+        }
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    }
+    h->prof_stage_ev.clear();
 }
 
 // ---------------------------------------------------------------------------
@@ -478,7 +492,10 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     if (rc) return rc;
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::vector<hipEvent_t> sev;
+    auto stamp = [&]() { if (h->prof) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, h->stream); sev.push_back(e); } };
     if (h->prof) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, h->stream); }
+    stamp();                                                   // start of A0
 
     // persistent A0/A1 workgroups: each owns slabs_per_wg consecutive slabs
     const uint64_t n_slabs = (n_tiles + (KB_THREADS / TPT) - 1) / (KB_THREADS / TPT);
@@ -493,10 +510,11 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     hipLaunchKernelGGL(kb_colscan_kernel, dim3(nbins), dim3(256), 0, h->stream, plan, s, (uint32_t)grid_a);
     hipLaunchKernelGGL(kb_scan1_kernel, dim3(1), dim3(KB_THREADS), 0, h->stream, plan, s, (uint32_t)CHUNK, h->ctl);
     HIPCHK(h, hipGetLastError());
+    stamp();                                                   // end of A0 (+ scans)
     HIPCHK(h, hipMemcpyAsync(h->kb_totals_host, s.totals, 32, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const uint64_t n_entries = h->kb_totals_host[0], n_chunks = h->kb_totals_host[1];
-    if (n_entries == 0) { if (h->prof) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); } return KDF_OK; }
+    if (n_entries == 0) { if (h->prof) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); for (hipEvent_t e : sev) (void)hipEventDestroy(e); } return KDF_OK; }
 
     const uint64_t nb_table = 1ull << (plan.c1 + plan.c2 + plan.sub_bits);
     if ((rc = kb_reserve(h, 0, n_entries * 8))) return rc;
@@ -509,7 +527,9 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     HIPCHK(h, hipMemsetAsync(s.failed, 0, failed_bytes, h->stream));
 
     hipLaunchKernelGGL(kb_scatter1_kernel<KW>, dim3(grid_a), dim3(KB_THREADS), lds_a1, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
+    stamp();                                                   // end of A1
     hipLaunchKernelGGL(kb_finesort_kernel<KW>, dim3((unsigned)n_chunks), dim3(KB_THREADS), lds_b, h->stream, plan, s);
+    stamp();                                                   // end of B
     if (filtered && (rc = materialize(h))) return rc;
     const int nonempty = h->lazy_empty ? 0 : 1;   // 0: kernel C rewrites every bucket (this IS the clear)
     if (filtered)
@@ -518,9 +538,11 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
         hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_INSERT>), dim3((unsigned)nb_table), dim3(KB_C_THREADS), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty);
     HIPCHK(h, hipGetLastError());
     if (h->prof) {
+        stamp();                                               // end of C
         (void)hipEventRecord(e1, h->stream);
         h->prof_ev.emplace_back(e0, e1);
         h->prof_tiles.push_back(n_tiles);
+        h->prof_stage_ev.push_back(sev);
     }
     HIPCHK(h, hipMemcpyAsync(h->kb_totals_host, s.totals, 72, hipMemcpyDeviceToHost, h->stream));
     bool full = false;
@@ -957,6 +979,34 @@ int kdf_export_ge(kdf_engine *h, uint32_t min_count, uint64_t *keys_lo_out, uint
     return KDF_OK;
 }
 
+int kdf_export_ge_dev(kdf_engine *h, uint32_t min_count, void *d_keys_lo_out, void *d_keys_hi_out,
+                      void *d_counts_out, uint64_t cap, int sorted, uint64_t *n_out) {
+    if (!h || !n_out) return fail(h, KDF_ERR_INVALID, "kdf_export_ge_dev: NULL pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    uint64_t n = 0;
+    int rc = export_pass(h, min_count, false, nullptr, nullptr, nullptr, 0, &n);
+    if (rc) return rc;
+    *n_out = n;
+    if (n == 0) return KDF_OK;
+    if (n > cap) return fail(h, KDF_ERR_INVALID, "kdf_export_ge_dev: %llu entries, room for %llu",
+                             (unsigned long long)n, (unsigned long long)cap);
+    if (!d_keys_lo_out || (h->kw == 2 && !d_keys_hi_out)) return fail(h, KDF_ERR_INVALID, "kdf_export_ge_dev: NULL key output");
+    uint64_t n2 = 0;
+    rc = export_pass(h, min_count, true, (uint64_t *)d_keys_lo_out, h->kw == 2 ? (uint64_t *)d_keys_hi_out : nullptr,
+                     (uint32_t *)d_counts_out, n, &n2);
+    if (rc) return rc;
+    if (n2 != n) return fail(h, KDF_ERR_STATE, "kdf_export_ge_dev: table changed between passes");
+    if (sorted) {
+        if (!d_counts_out) return fail(h, KDF_ERR_INVALID, "kdf_export_ge_dev: sorted export needs the counts array");
+        std::string serr;
+        if (kdf_sort_pairs_device((uint64_t *)d_keys_lo_out, h->kw == 2 ? (uint64_t *)d_keys_hi_out : nullptr,
+                                  (uint32_t *)d_counts_out, n, h->stream, serr))
+            return fail(h, KDF_ERR_HIP, "kdf_export_ge_dev: sort failed: %s", serr.c_str());
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return KDF_OK;
+}
+
 int kdf_scan_reads_dev(kdf_engine *h, const void *d_packed, const void *d_invalid, uint64_t n_bases, void *d_hit_bits) {
     if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
     if (n_bases == 0) return KDF_OK;
@@ -1034,6 +1084,16 @@ int kdf_profile(kdf_engine *h, int enable) {
     prof_collect(h);
     h->prof = enable != 0;
     h->prof_ms = 0.0; h->prof_launches = 0; h->prof_positions = 0;
+    for (double &m : h->prof_stage_ms) m = 0.0;
+    h->prof_stage_passes = 0;
+    return KDF_OK;
+}
+
+int kdf_profile_stages(kdf_engine *h, double *stage_ms4, uint64_t *passes) {
+    if (!h || !stage_ms4) return fail(h, KDF_ERR_INVALID, "kdf_profile_stages: NULL pointer");
+    prof_collect(h);
+    for (int i = 0; i < 4; ++i) stage_ms4[i] = h->prof_stage_ms[i];
+    if (passes) *passes = h->prof_stage_passes;
     return KDF_OK;
 }
 

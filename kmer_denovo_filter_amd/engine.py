@@ -102,6 +102,14 @@ class KmerEngine:
         self._ck(self._lib.kdf_profile_read(self._h, byref(ms), byref(n), byref(p)))
         return ms.value, n.value, p.value
 
+    def profile_stages(self):
+        """([A0 hist+scans, A1 scatter, B finesort, C bucket] summed ms, binned passes)."""
+        import ctypes
+        ms = (ctypes.c_double * 4)()
+        n = c_uint64(0)
+        self._ck(self._lib.kdf_profile_stages(self._h, ms, byref(n)))
+        return list(ms), n.value
+
     # -- count / filter ----------------------------------------------------
     def count(self, stream: ReadStream):
         self._ck(self._lib.kdf_count_reads(self._h, _vp(stream.packed), _vp(stream.invalid), stream.n_bases))
@@ -178,6 +186,16 @@ class KmerEngine:
         if got.value != n:
             raise _native.KdfError(_native.KDF_ERR_STATE, "export size changed between passes")
         return lo, hi, cnt
+
+    def export_ge_dev(self, min_count: int, d_lo: int, d_hi: Optional[int], d_cnt: Optional[int], cap: int,
+                      sorted_: bool = False) -> int:
+        """Dump into caller-owned device buffers; returns the number of entries."""
+        n = c_uint64(0)
+        self._ck(self._lib.kdf_export_ge_dev(self._h, int(min_count), c_void_p(d_lo),
+                                             c_void_p(d_hi) if d_hi else None,
+                                             c_void_p(d_cnt) if d_cnt else None, int(cap),
+                                             1 if sorted_ else 0, byref(n)))
+        return n.value
 
     # -- Module-3 scan -----------------------------------------------------
     def scan(self, stream: ReadStream, want_distinct: bool = True):
