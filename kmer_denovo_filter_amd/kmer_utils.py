@@ -53,6 +53,62 @@ def _extract_read_kmers(seq, kmer_size):
     return canon_at_pos, list(dict.fromkeys(candidates))
 
 
+class KmerAutomaton:
+    """Stand-in for the ``ahocorasick.Automaton`` that ``build_kmer_automaton``
+    returns in the reference (:41-65): ``iter(seq)`` yields ``(end_index,
+    canonical_kmer)`` for every window of *seq* whose canonical k-mer is in the
+    set, ``len()`` is the number of patterns (forward + distinct reverse
+    complements).  Backed by the engine's scan kernel; the table is created on
+    first use.  Unlike Aho-Corasick it matches case-insensitively (the reference's
+    AC backend is case-sensitive on the raw read, SURVEY.md "Known quirks")."""
+
+    def __init__(self, canonical_kmers, device: int = 0):
+        self._kmers = list(dict.fromkeys(canonical_kmers))
+        self.kmer_size = len(self._kmers[0])
+        if any(len(km) != self.kmer_size for km in self._kmers):
+            raise ValueError("k-mers of different lengths")
+        self._n_patterns = sum(1 if reverse_complement(km) == km else 2 for km in self._kmers)
+        self._device = device
+        self._engine: Optional[KmerEngine] = None
+
+    def __len__(self):
+        return self._n_patterns
+
+    def _ensure_engine(self) -> KmerEngine:
+        if self._engine is None:
+            lo, hi = kmers_to_keys(self._kmers, self.kmer_size, canonical=True)
+            eng = KmerEngine(self.kmer_size, capacity_hint=max(len(lo), 1), device=self._device)
+            eng.add_pairs(lo, hi, np.ones(len(lo), np.uint32))
+            self._engine = eng
+        return self._engine
+
+    def iter(self, seq):
+        k = self.kmer_size
+        if len(seq) < k:
+            return
+        eng = self._ensure_engine()
+        hits, _ = eng.scan(ReadStream.from_strings([seq]), want_distinct=False)
+        up = seq.upper()
+        for p in hit_positions(hits, 0, len(seq)).tolist():
+            yield p + k - 1, canonicalize(up[p:p + k])
+
+    def __del__(self):
+        try:
+            if self._engine is not None:
+                self._engine.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def build_kmer_automaton(canonical_kmers):
+    """Probe structure over a set of canonical k-mers, or ``None`` when the set is
+    empty (reference :41-65)."""
+    kmers = list(canonical_kmers)
+    if not kmers:
+        return None
+    return KmerAutomaton(kmers)
+
+
 class JellyfishKmerQuery:
     """Membership probe of canonical k-mers against an index file (reference
     :124-245).  *jf_path* may be a ``kdf/sorted`` index written by this package or
