@@ -99,14 +99,14 @@ def scan_bam_for_hits(child_bam, engine: Optional[KmerEngine] = None, min_dk_per
             out = []
             for r in np.flatnonzero(distinct >= max(min_dk, 1)).tolist():
                 s, e_ = int(batch.offsets[r]), int(batch.offsets[r + 1]) - 1
-                out.append(InformativeRead(batch.names[r], int(batch.flags[r]), int(batch.ref_ids[r]),
+                out.append(InformativeRead(batch.name(r), int(batch.flags[r]), int(batch.ref_ids[r]),
                                            int(batch.positions[r]), hit_positions(hits, s, e_),
                                            int(distinct[r])))
             if min_dk <= 0:
                 # reference: `len(unique_in_read) < min_dk_per_read` never true for 0 -> every read kept
                 keep = set(np.flatnonzero(distinct == 0).tolist())
                 for r in sorted(keep):
-                    out.append(InformativeRead(batch.names[r], int(batch.flags[r]), int(batch.ref_ids[r]),
+                    out.append(InformativeRead(batch.name(r), int(batch.flags[r]), int(batch.ref_ids[r]),
                                                int(batch.positions[r]), np.zeros(0, np.int64), 0))
             yield batch.n_reads, out
 

@@ -661,12 +661,6 @@ extern "C" {
 
 const char *kdf_last_error(const kdf_engine *h) { return h ? h->err.c_str() : g_err.c_str(); }
 
-void kdf_stream_words(uint64_t n_bases, uint64_t *packed_words, uint64_t *mask_words) {
-    const uint64_t tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
-    if (packed_words) *packed_words = tiles * 2 + 4;   // a tile reads words [2t, 2t+3]
-    if (mask_words) *mask_words = tiles + 2;           // and mask words [t, t+1]
-}
-
 int kdf_create(int device, int k, uint64_t capacity_hint, kdf_engine **out) {
     if (!out) return fail(nullptr, KDF_ERR_INVALID, "kdf_create: out is NULL");
     *out = nullptr;

@@ -7,11 +7,16 @@
 // CRAM is not supported.
 #include <zlib.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kdf.h"
@@ -32,29 +37,93 @@ const CodeTable kCode;
 // BAM 4-bit base code -> 2-bit code (A=1,C=2,G=4,T=8), 4 = invalid
 const uint8_t kNt16[16] = {4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4};
 
-// Appends bases to a (packed, invalid) stream under construction.
+// BAM packs two bases per byte (first base in the high nibble).  kSeq4[b] =
+// 2-bit codes of the two bases in bits 0-3 (first base in bits 0-1) and their
+// invalid flags in bits 4-5.
+struct Seq4Table {
+    uint8_t t[256];
+    Seq4Table() {
+        for (int b = 0; b < 256; ++b) {
+            const uint8_t c0 = kNt16[b >> 4], c1 = kNt16[b & 15];
+            t[b] = (uint8_t)((c0 < 4 ? c0 : 0) | ((c1 < 4 ? c1 : 0) << 2) | ((c0 > 3) << 4) | ((c1 > 3) << 5));
+        }
+    }
+};
+const Seq4Table kSeq4;
+
+// Appends bases to a (packed, invalid) stream under construction.  The arrays
+// must be zero on entry (begin() does that); finish() marks everything from the
+// end of the stream to the end of the arrays invalid.
 struct StreamWriter {
     uint64_t *packed;
     uint64_t *invalid;
     uint64_t n = 0;
+    uint64_t pw = 0, mw = 0;
     StreamWriter(uint64_t *p, uint64_t *m) : packed(p), invalid(m) {}
-    inline void put(uint8_t code) {           // code 0..3 valid, >= 4 invalid
-        const uint64_t i = n++;
-        if ((i & 31) == 0) packed[i >> 5] = 0;
-        if ((i & 63) == 0) invalid[i >> 6] = 0;
-        if (code < 4) packed[i >> 5] |= (uint64_t)code << ((i & 31) * 2);
-        else invalid[i >> 6] |= 1ull << (i & 63);
+    void begin(uint64_t capacity_bases) {
+        kdf_stream_words(capacity_bases, &pw, &mw);
+        memset(packed, 0, pw * 8);
+        memset(invalid, 0, mw * 8);
     }
-    // finish: mark the tail of the last mask word invalid
+    inline void put_bits(uint64_t codes, uint64_t inv, int nb) {   // nb bases (<= 16), LSB first
+        const uint64_t w = n >> 5; const int sh = (int)(n & 31) * 2;
+        packed[w] |= codes << sh;
+        if (sh + 2 * nb > 64) packed[w + 1] |= codes >> (64 - sh);
+        const uint64_t m = n >> 6; const int ms = (int)(n & 63);
+        invalid[m] |= inv << ms;
+        if (ms + nb > 64) invalid[m + 1] |= inv >> (64 - ms);
+        n += nb;
+    }
+    inline void put(uint8_t code) { put_bits(code < 4 ? code : 0, code > 3, 1); }
+    inline void put_sep() { put_bits(0, 1, 1); }
+    // BAM 4-bit sequence, l_seq bases
+    void put_seq4(const uint8_t *sq, int64_t l_seq) {
+        int64_t i = 0;
+        for (; i + 16 <= l_seq; i += 16) {                       // 8 bytes -> 16 bases per append
+            uint64_t codes = 0, inv = 0;
+            for (int j = 0; j < 8; ++j) {
+                const uint8_t v = kSeq4.t[sq[(i >> 1) + j]];
+                codes |= (uint64_t)(v & 15) << (4 * j);
+                inv |= (uint64_t)(v >> 4) << (2 * j);
+            }
+            put_bits(codes, inv, 16);
+        }
+        for (; i + 2 <= l_seq; i += 2) {
+            const uint8_t v = kSeq4.t[sq[i >> 1]];
+            put_bits(v & 15, v >> 4, 2);
+        }
+        if (i < l_seq) {
+            const uint8_t v = kSeq4.t[sq[i >> 1]];
+            put_bits(v & 3, (v >> 4) & 1, 1);
+        }
+    }
+    // ASCII bases
+    void put_ascii(const char *a, int64_t len) {
+        int64_t i = 0;
+        for (; i + 16 <= len; i += 16) {
+            uint64_t codes = 0, inv = 0;
+            for (int j = 0; j < 16; ++j) {
+                const uint8_t c = kCode.t[(uint8_t)a[i + j]];
+                codes |= (uint64_t)(c & 3) << (2 * j);
+                inv |= (uint64_t)(c > 3) << j;
+                if (c > 3) codes &= ~(3ull << (2 * j));
+            }
+            put_bits(codes, inv, 16);
+        }
+        for (; i < len; ++i) put(kCode.t[(uint8_t)a[i]]);
+    }
     void finish() {
         if (n & 63) invalid[n >> 6] |= ~0ull << (n & 63);
+        const uint64_t first = (n + 63) >> 6;
+        if (mw > first) memset(invalid + first, 0xFF, (mw - first) * 8);
     }
 };
 
 // ----------------------------------------------------------------- records --
 
 struct Record {
-    std::vector<uint8_t> codes;   // one 2-bit code (or 4) per base
+    std::vector<uint8_t> seq4;    // BAM 4-bit packed sequence (FASTA readers: unused)
+    int32_t l_seq = 0;
     std::string name;
     uint16_t flag = 0;
     int32_t ref_id = -1, pos = -1;
@@ -62,11 +131,150 @@ struct Record {
 
 }  // namespace
 
+namespace {
+
+struct BgzfBlock {
+    std::vector<uint8_t> comp;     // deflate payload + 8-byte trailer
+    std::vector<uint8_t> data;     // inflated
+    int cdata = 0;
+    uint32_t isize = 0;
+    int state = 0;                 // 0 free, 1 queued, 2 done, 3 error
+    std::string err;
+};
+
+// read one raw BGZF block.  returns 0 ok, 1 eof, -1 error (msg in err)
+int bgzf_read_raw(FILE *fp, BgzfBlock &blk, std::string &err) {
+    uint8_t hdr[18];
+    size_t got = fread(hdr, 1, 18, fp);
+    if (got == 0) return 1;
+    if (got != 18 || hdr[0] != 0x1f || hdr[1] != 0x8b || hdr[2] != 8 || !(hdr[3] & 4)) { err = "not a BGZF block (bad gzip header)"; return -1; }
+    const unsigned xlen = hdr[10] | (hdr[11] << 8);
+    // the BC subfield is normally first (xlen == 6); handle the general case
+    std::vector<uint8_t> extra(xlen);
+    memcpy(extra.data(), hdr + 12, std::min<unsigned>(6, xlen));
+    if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, fp) != xlen - 6) { err = "truncated BGZF extra field"; return -1; }
+    int bsize = -1;
+    for (unsigned o = 0; o + 4 <= xlen;) {
+        const unsigned slen = extra[o + 2] | (extra[o + 3] << 8);
+        if (extra[o] == 'B' && extra[o + 1] == 'C' && slen == 2 && o + 6 <= xlen) bsize = extra[o + 4] | (extra[o + 5] << 8);
+        o += 4 + slen;
+    }
+    if (bsize < 0) { err = "BGZF block without BC subfield"; return -1; }
+    const int cdata = bsize - (int)xlen - 19;
+    if (cdata < 0) { err = "corrupt BGZF block size"; return -1; }
+    blk.comp.resize((size_t)cdata + 8);
+    if (fread(blk.comp.data(), 1, blk.comp.size(), fp) != blk.comp.size()) { err = "truncated BGZF block"; return -1; }
+    blk.cdata = cdata;
+    const uint8_t *t = blk.comp.data() + cdata;
+    blk.isize = t[4] | (t[5] << 8) | (t[6] << 16) | ((uint32_t)t[7] << 24);
+    return 0;
+}
+
+// inflate blk.comp -> blk.data.  returns false on error (msg in blk.err)
+bool bgzf_inflate(BgzfBlock &blk) {
+    blk.data.resize(blk.isize);
+    if (blk.isize == 0) return true;
+    z_stream zs; memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) { blk.err = "inflateInit2 failed"; return false; }
+    zs.next_in = blk.comp.data(); zs.avail_in = (uInt)blk.cdata;
+    zs.next_out = blk.data.data(); zs.avail_out = blk.isize;
+    const int zr = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    if (zr != Z_STREAM_END || zs.avail_out != 0) { blk.err = "BGZF inflate failed"; return false; }
+    return true;
+}
+
+}  // namespace
+
+// Ordered, threaded BGZF decompression: one I/O thread reads raw blocks into a
+// ring, `nthreads` workers inflate them, the parser consumes them in file order
+// (what `samtools -@ n` does for the reference, core/jellyfish_wrappers.py:158-163).
+struct BgzfPool {
+    FILE *fp = nullptr;
+    std::vector<BgzfBlock> ring;
+    size_t head = 0, tail = 0;            // consume / fill sequence numbers
+    std::deque<size_t> work;
+    bool eof_read = false, stop = false, io_error = false;
+    std::string io_err;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done, cv_free;
+    std::thread io;
+    std::vector<std::thread> workers;
+
+    BgzfPool(FILE *f, int nthreads) : fp(f), ring((size_t)nthreads * 8) {
+        io = std::thread([this] { io_loop(); });
+        for (int i = 0; i < nthreads; ++i) workers.emplace_back([this] { work_loop(); });
+    }
+    ~BgzfPool() {
+        { std::lock_guard<std::mutex> g(mu); stop = true; }
+        cv_work.notify_all(); cv_free.notify_all(); cv_done.notify_all();
+        if (io.joinable()) io.join();
+        for (auto &t : workers) if (t.joinable()) t.join();
+    }
+    void io_loop() {
+        for (;;) {
+            size_t slot;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_free.wait(lk, [this] { return stop || tail - head < ring.size(); });
+                if (stop) return;
+                slot = tail % ring.size();
+            }
+            std::string err;
+            const int rc = bgzf_read_raw(fp, ring[slot], err);      // slot is free: no one else touches it
+            std::lock_guard<std::mutex> g(mu);
+            if (rc == 1) { eof_read = true; cv_done.notify_all(); return; }
+            if (rc < 0) { io_error = true; io_err = err; eof_read = true; cv_done.notify_all(); return; }
+            ring[slot].state = 1; ring[slot].err.clear();
+            work.push_back(tail);
+            ++tail;
+            cv_work.notify_one();
+        }
+    }
+    void work_loop() {
+        for (;;) {
+            size_t seq;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [this] { return stop || !work.empty(); });
+                if (stop) return;
+                seq = work.front(); work.pop_front();
+            }
+            BgzfBlock &blk = ring[seq % ring.size()];
+            const bool ok = bgzf_inflate(blk);
+            std::lock_guard<std::mutex> g(mu);
+            blk.state = ok ? 2 : 3;
+            cv_done.notify_all();
+        }
+    }
+    // append the next block's bytes to `out`.  0 ok, 1 eof, -1 error (msg in err)
+    int next(std::vector<uint8_t> &out, std::string &err) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [this] { return (head < tail && ring[head % ring.size()].state >= 2) || (eof_read && head == tail); });
+        if (head == tail) {
+            if (io_error) { err = io_err; return -1; }
+            return 1;
+        }
+        BgzfBlock &blk = ring[head % ring.size()];
+        if (blk.state == 3) { err = blk.err; return -1; }
+        lk.unlock();
+        out.insert(out.end(), blk.data.begin(), blk.data.end());
+        lk.lock();
+        blk.state = 0;
+        ++head;
+        cv_free.notify_one();
+        return 0;
+    }
+};
+
+
 struct kdf_reader {
     enum Kind { BAM, FASTA } kind = BAM;
     std::string err;
     // ---- BAM
     FILE *fp = nullptr;
+    std::unique_ptr<BgzfPool> pool;    // threaded inflate (threads > 1)
+    BgzfBlock blk;                     // synchronous inflate (threads <= 1)
     std::vector<uint8_t> inbuf;        // decompressed, not yet consumed
     size_t inpos = 0;
     bool eof = false;
@@ -78,6 +286,7 @@ struct kdf_reader {
     Record best[3];
     int score[3] = {-1, -1, -1};
     std::deque<Record> ready;          // records ready to be emitted
+    std::vector<Record> spare;         // recycled records (their buffers keep their capacity: no mallocs in steady state)
     // ---- FASTA
     gzFile gz = nullptr;
     int fasta_k = 0;
@@ -106,46 +315,26 @@ int rfail(kdf_reader *r, int code, const char *fmt, ...) {
 
 // ---- BGZF ------------------------------------------------------------------
 
-// read + inflate one BGZF block, append to r->inbuf.  returns 0 ok, 1 eof, <0 error
+// read + inflate the next BGZF block, append to r->inbuf.  returns 0 ok, 1 eof, <0 error
 int bgzf_read_block(kdf_reader *r) {
-    uint8_t hdr[18];
-    size_t got = fread(hdr, 1, 18, r->fp);
-    if (got == 0) return 1;
-    if (got != 18 || hdr[0] != 0x1f || hdr[1] != 0x8b || hdr[2] != 8 || !(hdr[3] & 4))
-        return rfail(r, -1, "not a BGZF block (bad gzip header)");
-    const unsigned xlen = hdr[10] | (hdr[11] << 8);
-    // the BC subfield is normally first (xlen == 6); handle the general case
-    std::vector<uint8_t> extra(xlen);
-    memcpy(extra.data(), hdr + 12, std::min<unsigned>(6, xlen));
-    if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, r->fp) != xlen - 6) return rfail(r, -1, "truncated BGZF extra field");
-    int bsize = -1;
-    for (unsigned o = 0; o + 4 <= xlen;) {
-        const unsigned slen = extra[o + 2] | (extra[o + 3] << 8);
-        if (extra[o] == 'B' && extra[o + 1] == 'C' && slen == 2 && o + 6 <= xlen) bsize = extra[o + 4] | (extra[o + 5] << 8);
-        o += 4 + slen;
-    }
-    if (bsize < 0) return rfail(r, -1, "BGZF block without BC subfield");
-    const int cdata = bsize - (int)xlen - 19;
-    if (cdata < 0) return rfail(r, -1, "corrupt BGZF block size");
-    std::vector<uint8_t> comp((size_t)cdata + 8);
-    if (fread(comp.data(), 1, comp.size(), r->fp) != comp.size()) return rfail(r, -1, "truncated BGZF block");
-    const uint32_t isize = comp[cdata + 4] | (comp[cdata + 5] << 8) | (comp[cdata + 6] << 16) | ((uint32_t)comp[cdata + 7] << 24);
-    if (isize == 0) return 0;
     // compact the consumed prefix now and then
     if (r->inpos > (1u << 20) && r->inpos * 2 > r->inbuf.size()) {
         r->inbuf.erase(r->inbuf.begin(), r->inbuf.begin() + r->inpos);
         r->inpos = 0;
     }
-    const size_t old = r->inbuf.size();
-    r->inbuf.resize(old + isize);
-    z_stream zs; memset(&zs, 0, sizeof zs);
-    if (inflateInit2(&zs, -15) != Z_OK) return rfail(r, -1, "inflateInit2 failed");
-    zs.next_in = comp.data(); zs.avail_in = (uInt)cdata;
-    zs.next_out = r->inbuf.data() + old; zs.avail_out = isize;
-    const int zr = inflate(&zs, Z_FINISH);
-    inflateEnd(&zs);
-    if (zr != Z_STREAM_END || zs.avail_out != 0) return rfail(r, -1, "BGZF inflate failed (%d)", zr);
-    return 0;
+    std::string err;
+    int rc;
+    if (r->pool) {
+        rc = r->pool->next(r->inbuf, err);
+    } else {
+        rc = bgzf_read_raw(r->fp, r->blk, err);
+        if (rc == 0) {
+            if (!bgzf_inflate(r->blk)) { rc = -1; err = r->blk.err; }
+            else r->inbuf.insert(r->inbuf.end(), r->blk.data.begin(), r->blk.data.end());
+        }
+    }
+    if (rc < 0) return rfail(r, -1, "%s", err.c_str());
+    return rc;
 }
 
 // make at least n bytes available at inpos; false at clean EOF / error
@@ -200,30 +389,35 @@ int bam_next_raw(kdf_reader *r, Record &rec, bool &has_qual) {
     if (l_seq < 0 || need > (size_t)bs) { rfail(r, KDF_ERR_IO, "corrupt BAM record (field sizes)"); return -1; }
     rec.name.assign((const char *)p + 32, l_rn ? l_rn - 1 : 0);
     const uint8_t *sq = p + 32 + l_rn + 4 * n_cig;
-    rec.codes.resize((size_t)l_seq);
-    for (int32_t i = 0; i < l_seq; ++i) {
-        const uint8_t b = sq[i >> 1];
-        rec.codes[i] = kNt16[(i & 1) ? (b & 0xF) : (b >> 4)];
-    }
+    rec.l_seq = l_seq;
+    rec.seq4.assign(sq, sq + ((size_t)l_seq + 1) / 2);
     has_qual = l_seq > 0 && sq[((size_t)l_seq + 1) / 2] != 0xFF;
     r->inpos += 4 + (size_t)bs;
     return 0;
 }
 
+inline Record grab(kdf_reader *r) {
+    if (r->spare.empty()) return Record();
+    Record x = std::move(r->spare.back());
+    r->spare.pop_back();
+    return x;
+}
+inline void recycle(kdf_reader *r, Record &&x) { if (r->spare.size() < 64) r->spare.push_back(std::move(x)); }
+
 void flush_run(kdf_reader *r) {
     for (int i = 0; i < 3; ++i)
-        if (r->score[i] >= 0) { r->ready.push_back(std::move(r->best[i])); r->best[i] = Record(); r->score[i] = -1; }
+        if (r->score[i] >= 0) { r->ready.push_back(std::move(r->best[i])); r->best[i] = grab(r); r->score[i] = -1; }
     r->have_run = false;
 }
 
 // fill r->ready with at least one record if any remain.  returns <0 on error.
 int bam_pump(kdf_reader *r) {
     while (r->ready.empty()) {
-        Record rec; bool hq = false;
+        Record rec = grab(r); bool hq = false;
         const int rc = bam_next_raw(r, rec, hq);
         if (rc < 0) return -1;
         if (rc == 1) { if (r->have_run) flush_run(r); return 0; }
-        if (rec.flag & r->flag_off) continue;
+        if (rec.flag & r->flag_off) { recycle(r, std::move(rec)); continue; }
         if (!r->collapse) { r->ready.push_back(std::move(rec)); return 0; }
         if (!r->have_run || rec.name != r->run_name) {
             if (r->have_run) flush_run(r);
@@ -232,7 +426,8 @@ int bam_pump(kdf_reader *r) {
         const bool r1 = rec.flag & 0x40, r2 = rec.flag & 0x80;
         const int part = (r1 && !r2) ? 1 : (r2 && !r1) ? 2 : 0;
         const int sc = hq ? 2 : 1;
-        if (sc > r->score[part]) { r->best[part] = std::move(rec); r->score[part] = sc; }
+        if (sc > r->score[part]) { std::swap(r->best[part], rec); r->score[part] = sc; }
+        recycle(r, std::move(rec));
     }
     return 0;
 }
@@ -264,6 +459,12 @@ void fasta_fill(kdf_reader *r, size_t want) {
 
 extern "C" {
 
+void kdf_stream_words(uint64_t n_bases, uint64_t *packed_words, uint64_t *mask_words) {
+    const uint64_t tiles = (n_bases + 63) / 64;        // a kernel tile = 64 window starts
+    if (packed_words) *packed_words = tiles * 2 + 4;   // a tile reads packed words [2t, 2t+3]
+    if (mask_words) *mask_words = tiles + 2;           // and mask words [t, t+1]
+}
+
 int kdf_canonical(const char *kmer, int k, uint64_t *lo, uint64_t *hi) {
     if (!kmer || k < 1 || k > 64) return KDF_ERR_INVALID;
     unsigned __int128 fwd = 0, rc = 0;
@@ -283,10 +484,11 @@ int kdf_pack_reads(const char *ascii, const int64_t *offsets, int64_t n_reads, u
                    uint64_t *invalid_out, int64_t *stream_offsets_out, uint64_t *n_bases_out) {
     if (n_reads < 0 || (n_reads && (!ascii || !offsets)) || !packed_out || !invalid_out) return KDF_ERR_INVALID;
     StreamWriter w(packed_out, invalid_out);
+    w.begin(n_reads ? (uint64_t)(offsets[n_reads] - offsets[0]) + (uint64_t)n_reads : 0);
     for (int64_t r = 0; r < n_reads; ++r) {
         if (stream_offsets_out) stream_offsets_out[r] = (int64_t)w.n;
-        for (int64_t i = offsets[r]; i < offsets[r + 1]; ++i) w.put(kCode.t[(uint8_t)ascii[i]]);
-        w.put(4);   // separator: no window spans two records
+        w.put_ascii(ascii + offsets[r], offsets[r + 1] - offsets[r]);
+        w.put_sep();   // separator: no window spans two records
     }
     if (stream_offsets_out) stream_offsets_out[n_reads] = (int64_t)w.n;
     w.finish();
@@ -297,7 +499,6 @@ int kdf_pack_reads(const char *ascii, const int64_t *offsets, int64_t n_reads, u
 const char *kdf_reader_error(const kdf_reader *r) { return r ? r->err.c_str() : g_host_err.c_str(); }
 
 int kdf_bam_open(const char *path, uint32_t flag_off, int collapse, int threads, kdf_reader **out) {
-    (void)threads;
     if (!path || !out) return rfail(nullptr, KDF_ERR_INVALID, "kdf_bam_open: NULL argument");
     *out = nullptr;
     kdf_reader *r = new kdf_reader();
@@ -307,6 +508,7 @@ int kdf_bam_open(const char *path, uint32_t flag_off, int collapse, int threads,
     if (!r->fp) { rfail(nullptr, KDF_ERR_IO, "cannot open %s", path); delete r; return KDF_ERR_IO; }
     static const size_t kBuf = 1 << 20;
     setvbuf(r->fp, nullptr, _IOFBF, kBuf);
+    if (threads > 1) r->pool.reset(new BgzfPool(r->fp, std::min(threads, 64)));
     int rc = bam_read_header(r);
     if (rc) { g_host_err = std::string(path) + ": " + r->err; kdf_reader_close(r); return rc; }
     *out = r;
@@ -328,6 +530,7 @@ int kdf_fasta_open(const char *path, int k, kdf_reader **out) {
 
 void kdf_reader_close(kdf_reader *r) {
     if (!r) return;
+    r->pool.reset();                   // joins the I/O and inflate threads before the file closes
     if (r->fp) fclose(r->fp);
     if (r->gz) gzclose(r->gz);
     delete r;
@@ -340,21 +543,23 @@ int kdf_reader_next(kdf_reader *r, uint64_t max_bases, int64_t max_reads, uint64
         return rfail(r, KDF_ERR_INVALID, "kdf_reader_next: bad argument");
     r->m_flags.clear(); r->m_ref.clear(); r->m_pos.clear(); r->m_names.clear(); r->m_name_off.clear();
     StreamWriter w(packed_out, invalid_out);
+    w.begin(max_bases);
     int64_t n = 0;
     if (r->kind == kdf_reader::BAM) {
         while (n < max_reads) {
             if (bam_pump(r) < 0) return KDF_ERR_IO;
             if (r->ready.empty()) break;
             Record &rec = r->ready.front();
-            if (rec.codes.size() + 1 > max_bases)
-                return rfail(r, KDF_ERR_INVALID, "read %s (%zu bases) exceeds max_bases", rec.name.c_str(), rec.codes.size());
-            if (w.n + rec.codes.size() + 1 > max_bases) break;
+            if ((uint64_t)rec.l_seq + 1 > max_bases)
+                return rfail(r, KDF_ERR_INVALID, "read %s (%d bases) exceeds max_bases", rec.name.c_str(), rec.l_seq);
+            if (w.n + (uint64_t)rec.l_seq + 1 > max_bases) break;
             if (stream_offsets_out) stream_offsets_out[n] = (int64_t)w.n;
-            for (uint8_t c : rec.codes) w.put(c);
-            w.put(4);
+            w.put_seq4(rec.seq4.data(), rec.l_seq);
+            w.put_sep();
             r->m_flags.push_back(rec.flag); r->m_ref.push_back(rec.ref_id); r->m_pos.push_back(rec.pos);
             r->m_name_off.push_back((int64_t)r->m_names.size());
             r->m_names.append(rec.name); r->m_names.push_back('\0');
+            recycle(r, std::move(rec));
             r->ready.pop_front();
             ++n;
         }
@@ -387,7 +592,7 @@ int kdf_reader_next(kdf_reader *r, uint64_t max_bases, int64_t max_reads, uint64
             const bool whole = r->fa_loaded_all && take == r->fa_codes.size();
             if (stream_offsets_out) stream_offsets_out[n] = (int64_t)w.n;
             for (size_t i = 0; i < take; ++i) w.put(r->fa_codes[i]);
-            w.put(4);
+            w.put_sep();
             r->m_flags.push_back(r->fa_continued ? 1 : 0); r->m_ref.push_back(-1); r->m_pos.push_back(-1);
             r->m_name_off.push_back((int64_t)r->m_names.size());
             r->m_names.append(r->fa_name); r->m_names.push_back('\0');

@@ -43,7 +43,19 @@ class ReadStream:
     flags: Optional[np.ndarray] = None
     ref_ids: Optional[np.ndarray] = None
     positions: Optional[np.ndarray] = None
-    names: Optional[List[str]] = None
+    name_buf: Optional[bytes] = None          # NUL-terminated names, back to back
+    name_offsets: Optional[np.ndarray] = None
+
+    def name(self, i: int) -> str:
+        o = int(self.name_offsets[i])
+        return self.name_buf[o:self.name_buf.index(b"\0", o)].decode()
+
+    @property
+    def names(self) -> Optional[List[str]]:
+        """All read names (decoded on demand: Module 3 only needs the few informative ones)."""
+        if self.name_buf is None:
+            return None
+        return [x.decode() for x in self.name_buf.split(b"\0")[:self.n_reads]]
 
     @property
     def n_reads(self) -> int:
@@ -115,9 +127,9 @@ class _Reader:
         lib = self._lib
         pw, mw = stream_words(self.max_bases)
         while self._h:
-            packed = np.zeros(pw, np.uint64)
-            invalid = np.full(mw, ~np.uint64(0), np.uint64)
-            so = np.zeros(self.max_reads + 1, np.int64)
+            packed = np.empty(pw, np.uint64)           # the native reader initialises both arrays
+            invalid = np.empty(mw, np.uint64)
+            so = np.empty(self.max_reads + 1, np.int64)
             n_reads, nb = c_int64(0), c_uint64(0)
             rc = lib.kdf_reader_next(self._h, self.max_bases, self.max_reads, _vp(packed), _vp(invalid),
                                      _vp(so), byref(n_reads), byref(nb))
@@ -127,9 +139,6 @@ class _Reader:
                 break
             pw_used, mw_used = stream_words(nb.value)
             st = ReadStream(packed[:pw_used], invalid[:mw_used], nb.value, so[:n + 1].copy())
-            # the reader only finishes the last mask word; restore padding defaults
-            st.packed[(nb.value + 31) // 32:] = 0
-            st.invalid[(nb.value + 63) // 64:] = ~np.uint64(0)
             if self.want_meta:
                 f, r, p = POINTER(c_uint16)(), POINTER(c_int32)(), POINTER(c_int32)()
                 nbuf, noff = c_char_p(), POINTER(c_int64)()
@@ -137,9 +146,12 @@ class _Reader:
                 st.flags = np.ctypeslib.as_array(f, (n,)).copy()
                 st.ref_ids = np.ctypeslib.as_array(r, (n,)).copy()
                 st.positions = np.ctypeslib.as_array(p, (n,)).copy()
-                offs = np.ctypeslib.as_array(noff, (n,))
+                offs = np.ctypeslib.as_array(noff, (n,)).copy()
                 base = ctypes.cast(nbuf, c_void_p).value
-                st.names = [ctypes.string_at(base + int(o)).decode() for o in offs]
+                last = int(offs[-1])
+                end = last + len(ctypes.string_at(base + last)) + 1
+                st.name_buf = ctypes.string_at(base, end)
+                st.name_offsets = offs
             yield st
         self.close()
 
