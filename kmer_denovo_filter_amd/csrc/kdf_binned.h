@@ -24,9 +24,10 @@
 #include "kdf_device.h"
 
 #define KB_THREADS   1024
-#define KB_F_BITS    8                   // fine bins per coarse bin (level-2 radix)
-#define KB_F         (1 << KB_F_BITS)
-#define KB_C1_MAX    9                   // coarse bins <= 512
+#define KB_F_BITS    8                   // preferred fine radix (level 2)
+#define KB_F_BITS_MAX 9                  // used only when the table has more buckets than 2^(C1_MAX+8)
+#define KB_F         (1 << KB_F_BITS_MAX)  // LDS array size for the fine histogram
+#define KB_C1_MAX    10                  // coarse bins <= 1024
 #define KB_C_THREADS 512                 // bucket kernel
 #define KB_C_RUNS    256                 // runs (chunks of the coarse bin) staged per round
 
@@ -39,6 +40,7 @@ struct KbPlan {
     uint32_t c2;            // fine bits (<= KB_F_BITS)
     uint32_t sub_bits;      // table buckets per partition bucket = 2^sub_bits
     uint32_t log2cap, bucket_bits;
+    uint32_t off_stride;    // entries per row of chunk_off = 2^c2 + 1
     uint32_t dbg;           // experiments only: 1 skip LDS insert, 2 skip gather loads, 4 skip write-back
 };
 
@@ -334,9 +336,9 @@ __global__ __launch_bounds__(KB_THREADS) void kb_finesort_kernel(KbPlan plan, Kb
         const uint32_t ex = kb_block_exscan(v, wsum, nullptr);
         if (threadIdx.x < nf) {
             offs[threadIdx.x] = ex;
-            s.chunk_off[chunk * (KB_F + 1) + threadIdx.x] = ex;
+            s.chunk_off[chunk * plan.off_stride + threadIdx.x] = ex;
         }
-        if (threadIdx.x == 0) s.chunk_off[chunk * (KB_F + 1) + nf] = len;
+        if (threadIdx.x == 0) s.chunk_off[chunk * plan.off_stride + nf] = len;
     }
     __syncthreads();
 #pragma unroll
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
         {
             const unsigned long long j = jb + threadIdx.x;
             if (threadIdx.x < KB_C_RUNS && j < j1) {
-                const uint32_t r0 = s.chunk_off[j * (KB_F + 1) + f], r1 = s.chunk_off[j * (KB_F + 1) + f + 1];
+                const uint32_t r0 = s.chunk_off[j * plan.off_stride + f], r1 = s.chunk_off[j * plan.off_stride + f + 1];
                 len = r1 - r0;
                 first = bstart + (j - j0) * (unsigned long long)CHUNK + r0;
             }

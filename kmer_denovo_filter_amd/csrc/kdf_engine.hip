@@ -450,9 +450,14 @@ static KbPlan kb_make_plan(const KdfTable &t) {
     KbPlan p{};
     p.log2cap = t.log2cap; p.bucket_bits = t.bucket_bits;
     const uint32_t nb_bits = t.log2cap - t.bucket_bits;
+    // prefer an 8-bit fine radix and <= 9 coarse bits (longest runs); widen only
+    // when the table has more buckets than that resolves
     p.c2 = std::min<uint32_t>(KB_F_BITS, nb_bits);
-    p.c1 = std::min<uint32_t>(KB_C1_MAX, nb_bits - p.c2);
+    p.c1 = std::min<uint32_t>(9, nb_bits - p.c2);
+    if (p.c1 + p.c2 < nb_bits) p.c2 = std::min<uint32_t>(KB_F_BITS_MAX, nb_bits - p.c1);   // fine runs halve: still >= 256 B
+    if (p.c1 + p.c2 < nb_bits) p.c1 = std::min<uint32_t>(KB_C1_MAX, nb_bits - p.c2);      // coarse runs halve: last resort
     p.sub_bits = nb_bits - p.c1 - p.c2;
+    p.off_stride = (1u << p.c2) + 1;
     return p;
 }
 
@@ -519,7 +524,7 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     const uint64_t nb_table = 1ull << (plan.c1 + plan.c2 + plan.sub_bits);
     if ((rc = kb_reserve(h, 0, n_entries * 8))) return rc;
     if (KW == 2 && (rc = kb_reserve(h, 1, n_entries * 8))) return rc;
-    if ((rc = kb_reserve(h, 2, n_chunks * (KB_F + 1) * 4))) return rc;
+    if ((rc = kb_reserve(h, 2, n_chunks * (size_t)plan.off_stride * 4))) return rc;
     const size_t failed_bytes = (size_t)((nb_table + 31) / 32) * 4;
     if ((rc = kb_reserve(h, 3, failed_bytes))) return rc;
     s.ent_lo = (uint64_t *)h->kb_buf[0]; s.ent_hi = (uint64_t *)h->kb_buf[1];
@@ -588,8 +593,9 @@ static int count_insert_dev(kdf_engine *h, const uint64_t *d_packed, const uint6
         int rc = h->kw == 1 ? kb_pass<1>(h, d_packed, d_invalid, n_bases, false)
                             : kb_pass<2>(h, d_packed, d_invalid, n_bases, false);
         if (rc) return rc;
-        // keep the load <= 0.6 for the next batch
-        while (h->distinct * 10 > h->cap * 6) {
+        // keep the load <= 0.7 for the next batch (a 2048-slot bucket then holds
+        // 1434 +- 38 keys: overflow, which is handled anyway, stays a rare event)
+        while (h->distinct * 10 > h->cap * 7) {
             if ((rc = table_rehash(h, h->t.log2cap + 1))) return rc;
         }
         return KDF_OK;
