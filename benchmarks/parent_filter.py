@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[2] / SURVEY.md section 8d item 3: the discovery
+parent-filter chain at chr20 scale on ONE MI355X.  The reference ships no chr20
+subset (its examples download ~500 GB), so the input is the synthetic trio the
+survey specifies: a 64 Mbp uniform genome (seed 20260418), child / mother /
+father at 30x of 150 bp reads (12.8 M reads each), 0.1 % child-private SNVs.
+
+Stages timed (streams resident in HBM, engine API only):
+  ref index        count the genome                      (_ensure_ref_jf)
+  child count      count -C                              (_extract_child_kmers_discovery)
+  dump -L 3        candidates                            (jellyfish dump)
+  ref subtract     query candidates against the ref      (_subtract_reference_kmers)
+  mother / father  count --if + query + <= parent_max    (_filter_parents_discovery)
+Prints one JSON object with per-stage ms and Gk-mer/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run(genome_len, coverage, k, seed, device, snv_rate=0.001, min_child_count=3, parent_max_count=0, verbose=True):
+    import numpy as np
+    import torch
+    from kmer_denovo_filter_amd import KmerEngine
+    from kmer_denovo_filter_amd.synth import genome_stream, plant_snvs, synth_genome, synth_stream
+
+    L = 150
+    n_reads = genome_len * coverage // L
+    g = synth_genome(genome_len, seed, device)
+    gc = plant_snvs(g, snv_rate, seed + 1)
+    streams = {
+        "ref": genome_stream(g),
+        "child": synth_stream(n_reads, L, seed=seed + 10, device=device, genome=gc),
+        "mother": synth_stream(n_reads, L, seed=seed + 20, device=device, genome=g),
+        "father": synth_stream(n_reads, L, seed=seed + 30, device=device, genome=g),
+    }
+    torch.cuda.synchronize()
+    out = {"genome": genome_len, "coverage": coverage, "k": k, "reads_per_sample": n_reads, "stages": {}}
+
+    def timed(name, fn, windows=None):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["stages"][name] = {"ms": round(dt * 1e3, 3)}
+        if windows:
+            out["stages"][name]["Gkmer_per_s"] = round(windows / dt / 1e9, 2)
+        return r
+
+    def count(eng, ds):
+        eng.count_dev(ds.packed.data_ptr(), ds.invalid.data_ptr(), ds.n_bases)
+        eng.synchronize()
+        return eng.stats()[2]
+
+    ref = KmerEngine(k, capacity_hint=genome_len)
+    w_ref = timed("ref_index", lambda: count(ref, streams["ref"]))
+    child = KmerEngine(k, capacity_hint=max(1 << 20, genome_len * 6))
+    w_child = timed("child_count", lambda: count(child, streams["child"]))
+    out["stages"]["child_count"]["Gkmer_per_s"] = round(w_child / (out["stages"]["child_count"]["ms"] * 1e-3) / 1e9, 2)
+    cand = timed("dump_L", lambda: child.export_ge(min_child_count))
+    out["child_windows"], out["child_distinct"], out["candidates"] = w_child, child.stats()[1], len(cand[0])
+    child.close()
+    refc = timed("ref_subtract", lambda: ref.query(cand[0], cand[1]))
+    keep = refc == 0
+    lo, hi = cand[0][keep], cand[1][keep]
+    out["non_ref"] = len(lo)
+    ref.close()
+    for label in ("mother", "father"):
+        eng = KmerEngine(k, capacity_hint=max(len(lo), 1))
+        ds = streams[label]
+
+        def stage():
+            eng.load_filter(lo, hi)
+            eng.count_filtered_dev(ds.packed.data_ptr(), ds.invalid.data_ptr(), ds.n_bases)
+            return eng.query(lo, hi)
+        c = timed(f"{label}_count_if", stage)
+        w = int(n_reads * (L - k + 1) * 0.964)
+        out["stages"][f"{label}_count_if"]["Gkmer_per_s"] = round(w / (out["stages"][f"{label}_count_if"]["ms"] * 1e-3) / 1e9, 2)
+        out["stages"][f"{label}_count_if"]["filter_keys"] = len(lo)
+        eng.close()
+        keep = c <= parent_max_count
+        lo, hi = lo[keep], hi[keep]
+        out[f"after_{label}"] = len(lo)
+    out["proband_unique"] = len(lo)
+    return out, (lo, hi), streams
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--genome", type=int, default=64_000_000)
+    ap.add_argument("--coverage", type=int, default=30)
+    ap.add_argument("--k", type=int, default=31)
+    args = ap.parse_args()
+    res, _, _ = run(args.genome, args.coverage, args.k, 20260418, "cuda:0")
+    print(json.dumps(res))

@@ -26,19 +26,61 @@ def _stream_words(n_bases: int):
     return tiles * 2 + 4, tiles + 2
 
 
+def synth_genome(genome_len: int, seed: int, device="cuda") -> torch.Tensor:
+    dev = torch.device(device)
+    gg = torch.Generator(device=dev)
+    gg.manual_seed(seed)
+    return torch.randint(0, 4, (genome_len,), dtype=torch.uint8, device=dev, generator=gg)
+
+
+def plant_snvs(genome: torch.Tensor, rate: float, seed: int) -> torch.Tensor:
+    """Copy of ``genome`` with a fraction ``rate`` of positions substituted
+    (the child-private variants of the synthetic trio)."""
+    g = torch.Generator(device=genome.device)
+    g.manual_seed(seed)
+    hit = torch.rand(genome.numel(), device=genome.device, generator=g) < rate
+    alt = torch.randint(1, 4, (genome.numel(),), dtype=torch.uint8, device=genome.device, generator=g)
+    return torch.where(hit, (genome + alt) & 3, genome)
+
+
+def genome_stream(genome: torch.Tensor) -> DeviceStream:
+    """The genome itself as one record (for the reference index)."""
+    dev = genome.device
+    n = genome.numel() + 1
+    pw, mw = _stream_words(n)
+    pad = (-n) % 64
+    codes = torch.cat([genome, torch.zeros(1 + pad, dtype=torch.uint8, device=dev)])
+    inv = torch.zeros(n + pad, dtype=torch.bool, device=dev)
+    inv[genome.numel():] = True
+    sh2 = (2 * torch.arange(32, device=dev, dtype=torch.int64))
+    sh1 = torch.arange(64, device=dev, dtype=torch.int64)
+    packed = torch.zeros(pw, dtype=torch.int64, device=dev)
+    invalid = torch.full((mw,), -1, dtype=torch.int64, device=dev)
+    step = 1 << 24
+    for a in range(0, n + pad, step):
+        b = min(n + pad, a + step)
+        w = (codes[a:b].reshape(-1, 32).to(torch.int64) << sh2[None, :]).sum(dim=1)
+        m = (inv[a:b].reshape(-1, 64).to(torch.int64) << sh1[None, :]).sum(dim=1)
+        packed[a // 32: a // 32 + w.numel()] = w
+        invalid[a // 64: a // 64 + m.numel()] = m
+    return DeviceStream(packed, invalid, n, 1, genome.numel())
+
+
 def synth_stream(n_reads: int, read_len: int = 150, genome_len: int = 100_000_000,
                  seed: int = 20260417, device="cuda", sub_rate: float = 0.005,
                  n_rate: float = 0.001, chunk_reads: int = 1 << 19,
-                 genome_seed: int | None = None) -> DeviceStream:
+                 genome_seed: int | None = None, genome: torch.Tensor | None = None) -> DeviceStream:
     """Returns the packed stream of ``n_reads`` synthetic reads on ``device``.
 
     ``genome_seed`` (default: ``seed``) fixes the genome; ranks of a multi-GPU
-    run share the genome and differ in ``seed`` (their read shard).
+    run share the genome and differ in ``seed`` (their read shard).  An explicit
+    ``genome`` tensor (uint8 codes) overrides both.
     """
     dev = torch.device(device)
-    gg = torch.Generator(device=dev)
-    gg.manual_seed(seed if genome_seed is None else genome_seed)
-    genome = torch.randint(0, 4, (genome_len,), dtype=torch.uint8, device=dev, generator=gg)
+    if genome is None:
+        genome = synth_genome(genome_len, seed if genome_seed is None else genome_seed, dev)
+    else:
+        genome_len = genome.numel()
     g = torch.Generator(device=dev)
     g.manual_seed(seed + 1)
     L1 = read_len + 1

@@ -55,3 +55,83 @@ def test_full_size_paths_agree_and_conserve():
     np.testing.assert_array_equal(out[0][0], out[1][0])
     np.testing.assert_array_equal(out[0][1], out[1][1])
     assert out[0][2] == out[1][2]
+
+
+def test_parent_filter_chain_synthetic_trio(oracle):
+    """BASELINE configs[2] at reduced size (1 Mbp genome, 20x): the surviving
+    proband-unique SET equals the oracle's discovery chain on the same reads."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "benchmarks"))
+    import parent_filter
+    from kmer_denovo_filter_amd.synth import stream_to_ascii
+    res, (lo, hi), streams = parent_filter.run(1_000_000, 20, 31, 20260418, "cuda:0")
+    asc = {}
+    for name in ("child", "mother", "father"):
+        asc[name] = stream_to_ascii(streams[name], streams[name].n_reads)
+    gbuf, goffs = stream_to_ascii(streams["ref"], 1)
+    rt = oracle.OracleTable(31, 1 << 21).count_reads((gbuf, goffs))
+    exp = oracle.discovery_chain(asc["child"], asc["mother"], asc["father"], rt, 31, 3, 0)
+    assert res["candidates"] == len(exp["candidates"][0])
+    assert res["non_ref"] == len(exp["non_ref"][0])
+    assert res["after_mother"] == len(exp["after_mother"][0])
+    np.testing.assert_array_equal(np.sort(lo), exp["proband_unique"][0])
+    assert res["proband_unique"] > 0                      # the planted SNVs are found
+
+
+def test_owner_exchange_gpu_pieces_two_virtual_ranks(oracle):
+    """Everything OwnerPartitionedCount does on the GPU except the RCCL call:
+    two engines count two read shards, their pairs are dumped on the device,
+    split by owner_of, routed in-process, and summed by two owner engines.  The
+    union must equal the oracle's global count; ownership must be exclusive."""
+    import torch
+    from kmer_denovo_filter_amd import KmerEngine
+    from kmer_denovo_filter_amd.distributed import EngineOps, ShardedFilterCount, owner_of
+    from kmer_denovo_filter_amd.synth import stream_to_ascii, synth_genome, synth_stream
+    dev = torch.device("cuda:0")
+    world = 2
+    g = synth_genome(2_000_000, 5, dev)
+    shards = [synth_stream(40_000, 150, seed=100 + r, device=dev, genome=g) for r in range(world)]
+    torch.cuda.synchronize()
+    for k in (31, 45):
+        local = [EngineOps(KmerEngine(k, capacity_hint=1 << 22), dev) for _ in range(world)]
+        owner = [EngineOps(KmerEngine(k, capacity_hint=1 << 22), dev) for _ in range(world)]
+        outbox = [[None] * world for _ in range(world)]
+        for r in range(world):
+            local[r].count_stream(shards[r].packed, shards[r].invalid, shards[r].n_bases)
+            lo, hi, cnt = local[r].export_pairs(0)
+            own = owner_of(lo, hi, world)
+            for d in range(world):
+                m = own == d
+                outbox[r][d] = (lo[m], hi[m] if hi is not None else None, cnt[m])
+        for d in range(world):
+            for r in range(world):
+                owner[d].add_pairs(*outbox[r][d])
+        allreads = []
+        for r in range(world):
+            buf, offs = stream_to_ascii(shards[r], shards[r].n_reads)
+            allreads.append((buf, offs))
+        ot = oracle.OracleTable(k, 1 << 22)
+        for br in allreads:
+            ot.count_reads(br)
+        elo, ehi, ecnt = ot.export_ge(0)
+        got_lo, got_hi, got_cnt = [], [], []
+        for d in range(world):
+            lo, hi, cnt = owner[d].e.export_ge(0)
+            t_lo = torch.from_numpy(lo.view(np.int64))
+            t_hi = torch.from_numpy(hi.view(np.int64)) if k > 32 else None
+            assert bool((owner_of(t_lo, t_hi, world) == d).all())
+            got_lo.append(lo); got_hi.append(hi); got_cnt.append(cnt)
+        lo = np.concatenate(got_lo); hi = np.concatenate(got_hi); cnt = np.concatenate(got_cnt)
+        order = np.lexsort((lo, hi))
+        np.testing.assert_array_equal(lo[order], elo)
+        np.testing.assert_array_equal(hi[order], ehi)
+        np.testing.assert_array_equal(cnt[order], ecnt)
+        # count --if merge with a 1-rank group object: query path + clamp
+        sfc = ShardedFilterCount(local[0])
+        tl = torch.from_numpy(elo[:1000].view(np.int64).copy()).to(dev)
+        th = torch.from_numpy(ehi[:1000].view(np.int64).copy()).to(dev) if k > 32 else None
+        merged = sfc.merged_counts(tl, th).cpu().numpy()
+        exp_local = oracle.OracleTable(k, 1 << 22).count_reads(allreads[0]).query(elo[:1000], ehi[:1000])
+        np.testing.assert_array_equal(merged, exp_local.astype(np.int64))
+        for o in local + owner:
+            o.e.close()
