@@ -234,6 +234,18 @@ int kdf_reader_next(kdf_reader *r, uint64_t max_bases, int64_t max_reads,
 int kdf_reader_last_meta(kdf_reader *r, const uint16_t **flags, const int32_t **ref_ids,
                          const int32_t **positions, const char **name_buf,
                          const int64_t **name_offsets);
+/* Alignment details for Module 3's post-processing of informative reads
+ * (core/bam_scanner.py:97-117,284-337: CIGAR -> reference coordinates, SA tag,
+ * soft clips).  Call kdf_reader_want_aux(r, 1) after kdf_bam_open; then, for the
+ * last batch: cigar[cigar_offsets[i] .. cigar_offsets[i+1]) are record i's CIGAR
+ * operations in BAM encoding (len << 4 | op), sa_offsets[i] is the offset of its
+ * NUL-terminated SA:Z value in sa_buf or -1. */
+int kdf_reader_want_aux(kdf_reader *r, int enable);
+int kdf_reader_last_aux(kdf_reader *r, const uint32_t **cigar, const int64_t **cigar_offsets,
+                        const char **sa_buf, const int64_t **sa_offsets);
+/* Reference sequence names of a BAM reader (header order = ref_id). */
+int kdf_reader_ref_count(kdf_reader *r);
+const char *kdf_reader_ref_name(kdf_reader *r, int i);
 void kdf_reader_close(kdf_reader *r);
 const char *kdf_reader_error(const kdf_reader *r);
 

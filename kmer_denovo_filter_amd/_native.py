@@ -54,6 +54,11 @@ SYMBOLS = [
     ("kdf_reader_next", c_int, [_P, c_uint64, c_int64, _P, _P, _P, POINTER(c_int64), POINTER(c_uint64)]),
     ("kdf_reader_last_meta", c_int, [_P, POINTER(POINTER(c_uint16)), POINTER(POINTER(c_int32)),
                                      POINTER(POINTER(c_int32)), POINTER(c_char_p), POINTER(POINTER(c_int64))]),
+    ("kdf_reader_want_aux", c_int, [_P, c_int]),
+    ("kdf_reader_last_aux", c_int, [_P, POINTER(POINTER(c_uint32)), POINTER(POINTER(c_int64)),
+                                    POINTER(c_char_p), POINTER(POINTER(c_int64))]),
+    ("kdf_reader_ref_count", c_int, [_P]),
+    ("kdf_reader_ref_name", c_char_p, [_P, c_int]),
     ("kdf_reader_close", None, [_P]),
     ("kdf_reader_error", c_char_p, [_P]),
 ]

@@ -127,6 +127,10 @@ struct Record {
     std::string name;
     uint16_t flag = 0;
     int32_t ref_id = -1, pos = -1;
+    // only filled when the reader was asked for alignment details (kdf_reader_want_aux)
+    std::vector<uint32_t> cigar;  // BAM encoding: len << 4 | op
+    std::string sa;               // SA:Z tag value, empty when absent
+    bool has_sa = false;
 };
 
 }  // namespace
@@ -302,6 +306,12 @@ struct kdf_reader {
     std::vector<int32_t> m_ref, m_pos;
     std::string m_names;
     std::vector<int64_t> m_name_off;
+    bool want_aux = false;
+    std::vector<uint32_t> m_cigar;
+    std::vector<int64_t> m_cigar_off;   // n_reads + 1
+    std::string m_sa;                   // NUL-terminated SA strings, back to back
+    std::vector<int64_t> m_sa_off;      // n_reads; -1 = no SA tag
+    std::vector<std::string> ref_names;
 };
 
 namespace {
@@ -366,6 +376,7 @@ int bam_read_header(kdf_reader *r) {
         if (!bam_need(r, 4, &e)) return rfail(r, KDF_ERR_IO, "truncated BAM reference list");
         const int32_t l_name = le32(r->inbuf.data() + r->inpos);
         if (!bam_need(r, 8 + (size_t)l_name, &e)) return rfail(r, KDF_ERR_IO, "truncated BAM reference list");
+        r->ref_names.emplace_back((const char *)r->inbuf.data() + r->inpos + 4, l_name > 0 ? (size_t)l_name - 1 : 0);
         r->inpos += 8 + (size_t)l_name;
     }
     return KDF_OK;
@@ -392,6 +403,36 @@ int bam_next_raw(kdf_reader *r, Record &rec, bool &has_qual) {
     rec.l_seq = l_seq;
     rec.seq4.assign(sq, sq + ((size_t)l_seq + 1) / 2);
     has_qual = l_seq > 0 && sq[((size_t)l_seq + 1) / 2] != 0xFF;
+    rec.cigar.clear(); rec.sa.clear(); rec.has_sa = false;
+    if (r->want_aux) {
+        const uint8_t *cg = p + 32 + l_rn;
+        rec.cigar.resize(n_cig);
+        for (unsigned i = 0; i < n_cig; ++i) rec.cigar[i] = (uint32_t)le32(cg + 4 * i);
+        // walk the optional fields for SA:Z
+        const uint8_t *a = p + need, *end = p + bs;
+        while (a + 3 <= end) {
+            const char t0 = (char)a[0], t1 = (char)a[1], ty = (char)a[2];
+            a += 3;
+            size_t len = 0;
+            if (ty == 'A' || ty == 'c' || ty == 'C') len = 1;
+            else if (ty == 's' || ty == 'S') len = 2;
+            else if (ty == 'i' || ty == 'I' || ty == 'f') len = 4;
+            else if (ty == 'Z' || ty == 'H') {
+                const uint8_t *z = a;
+                while (z < end && *z) ++z;
+                if (t0 == 'S' && t1 == 'A' && ty == 'Z') { rec.sa.assign((const char *)a, (size_t)(z - a)); rec.has_sa = true; }
+                len = (size_t)(z - a) + 1;
+            } else if (ty == 'B') {
+                if (a + 5 > end) break;
+                const char sub = (char)a[0];
+                const uint32_t cnt = (uint32_t)le32(a + 1);
+                const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                len = 5 + es * (size_t)cnt;
+            } else break;                                   // unknown type: stop parsing
+            if (a + len > end) break;
+            a += len;
+        }
+    }
     r->inpos += 4 + (size_t)bs;
     return 0;
 }
@@ -542,6 +583,7 @@ int kdf_reader_next(kdf_reader *r, uint64_t max_bases, int64_t max_reads, uint64
     if (!r || !packed_out || !invalid_out || !n_reads_out || !n_bases_out || max_reads < 1)
         return rfail(r, KDF_ERR_INVALID, "kdf_reader_next: bad argument");
     r->m_flags.clear(); r->m_ref.clear(); r->m_pos.clear(); r->m_names.clear(); r->m_name_off.clear();
+    r->m_cigar.clear(); r->m_cigar_off.clear(); r->m_sa.clear(); r->m_sa_off.clear();
     StreamWriter w(packed_out, invalid_out);
     w.begin(max_bases);
     int64_t n = 0;
@@ -559,6 +601,12 @@ int kdf_reader_next(kdf_reader *r, uint64_t max_bases, int64_t max_reads, uint64
             r->m_flags.push_back(rec.flag); r->m_ref.push_back(rec.ref_id); r->m_pos.push_back(rec.pos);
             r->m_name_off.push_back((int64_t)r->m_names.size());
             r->m_names.append(rec.name); r->m_names.push_back('\0');
+            if (r->want_aux) {
+                r->m_cigar_off.push_back((int64_t)r->m_cigar.size());
+                r->m_cigar.insert(r->m_cigar.end(), rec.cigar.begin(), rec.cigar.end());
+                if (rec.has_sa) { r->m_sa_off.push_back((int64_t)r->m_sa.size()); r->m_sa.append(rec.sa); r->m_sa.push_back('\0'); }
+                else r->m_sa_off.push_back(-1);
+            }
             recycle(r, std::move(rec));
             r->ready.pop_front();
             ++n;
@@ -605,6 +653,7 @@ int kdf_reader_next(kdf_reader *r, uint64_t max_bases, int64_t max_reads, uint64
         }
     }
     if (stream_offsets_out) stream_offsets_out[n] = (int64_t)w.n;
+    if (r->want_aux) r->m_cigar_off.push_back((int64_t)r->m_cigar.size());
     w.finish();
     *n_reads_out = n;
     *n_bases_out = w.n;
@@ -620,6 +669,29 @@ int kdf_reader_last_meta(kdf_reader *r, const uint16_t **flags, const int32_t **
     if (name_buf) *name_buf = r->m_names.data();
     if (name_offsets) *name_offsets = r->m_name_off.data();
     return KDF_OK;
+}
+
+int kdf_reader_want_aux(kdf_reader *r, int enable) {
+    if (!r || r->kind != kdf_reader::BAM) return KDF_ERR_INVALID;
+    r->want_aux = enable != 0;
+    return KDF_OK;
+}
+
+int kdf_reader_last_aux(kdf_reader *r, const uint32_t **cigar, const int64_t **cigar_offsets,
+                        const char **sa_buf, const int64_t **sa_offsets) {
+    if (!r || !r->want_aux) return KDF_ERR_INVALID;
+    if (cigar) *cigar = r->m_cigar.data();
+    if (cigar_offsets) *cigar_offsets = r->m_cigar_off.data();
+    if (sa_buf) *sa_buf = r->m_sa.data();
+    if (sa_offsets) *sa_offsets = r->m_sa_off.data();
+    return KDF_OK;
+}
+
+int kdf_reader_ref_count(kdf_reader *r) { return r ? (int)r->ref_names.size() : -1; }
+
+const char *kdf_reader_ref_name(kdf_reader *r, int i) {
+    if (!r || i < 0 || i >= (int)r->ref_names.size()) return nullptr;
+    return r->ref_names[(size_t)i].c_str();
 }
 
 }  // extern "C"

@@ -45,6 +45,22 @@ class ReadStream:
     positions: Optional[np.ndarray] = None
     name_buf: Optional[bytes] = None          # NUL-terminated names, back to back
     name_offsets: Optional[np.ndarray] = None
+    # alignment details (bam_reader(..., want_aux=True))
+    cigar: Optional[np.ndarray] = None        # uint32, BAM encoding (len << 4 | op), all records back to back
+    cigar_offsets: Optional[np.ndarray] = None  # int64[n_reads + 1]
+    sa_buf: Optional[bytes] = None
+    sa_offsets: Optional[np.ndarray] = None   # int64[n_reads], -1 = no SA tag
+
+    def cigartuples(self, i: int):
+        """[(op, length), ...] of record i, as pysam's ``cigartuples``."""
+        c = self.cigar[int(self.cigar_offsets[i]):int(self.cigar_offsets[i + 1])]
+        return [(int(x) & 0xF, int(x) >> 4) for x in c]
+
+    def sa_tag(self, i: int):
+        o = int(self.sa_offsets[i])
+        if o < 0:
+            return None
+        return self.sa_buf[o:self.sa_buf.index(b"\0", o)].decode()
 
     def name(self, i: int) -> str:
         o = int(self.name_offsets[i])
@@ -102,12 +118,19 @@ class ReadStream:
 class _Reader:
     """Iterator over ReadStream batches from a native kdf_reader."""
 
-    def __init__(self, handle, max_bases: int, max_reads: int, want_meta: bool):
+    def __init__(self, handle, max_bases: int, max_reads: int, want_meta: bool, want_aux: bool = False):
         self._h = handle
         self.max_bases = int(max_bases)
         self.max_reads = int(max_reads)
-        self.want_meta = want_meta
+        self.want_meta = want_meta or want_aux
+        self.want_aux = want_aux
         self._lib = _native.load()
+        if want_aux:
+            _native.check_reader(self._lib.kdf_reader_want_aux(self._h, 1), self._h)
+
+    def references(self) -> List[str]:
+        n = self._lib.kdf_reader_ref_count(self._h)
+        return [self._lib.kdf_reader_ref_name(self._h, i).decode() for i in range(max(n, 0))]
 
     def close(self):
         if self._h:
@@ -152,18 +175,35 @@ class _Reader:
                 end = last + len(ctypes.string_at(base + last)) + 1
                 st.name_buf = ctypes.string_at(base, end)
                 st.name_offsets = offs
+            if self.want_aux:
+                from ctypes import c_uint32
+                cg, cgo = POINTER(c_uint32)(), POINTER(c_int64)()
+                sab, sao = c_char_p(), POINTER(c_int64)()
+                _native.check_reader(lib.kdf_reader_last_aux(self._h, byref(cg), byref(cgo), byref(sab), byref(sao)),
+                                     self._h)
+                st.cigar_offsets = np.ctypeslib.as_array(cgo, (n + 1,)).copy()
+                ncg = int(st.cigar_offsets[-1])
+                st.cigar = np.ctypeslib.as_array(cg, (ncg,)).copy() if ncg else np.zeros(0, np.uint32)
+                st.sa_offsets = np.ctypeslib.as_array(sao, (n,)).copy()
+                valid = st.sa_offsets[st.sa_offsets >= 0]
+                if len(valid):
+                    sbase = ctypes.cast(sab, c_void_p).value
+                    last = int(valid.max())
+                    st.sa_buf = ctypes.string_at(sbase, last + len(ctypes.string_at(sbase + last)) + 1)
+                else:
+                    st.sa_buf = b""
             yield st
         self.close()
 
 
 def bam_reader(path: str, flag_off: int = FLAG_OFF_SAMTOOLS_FASTA, collapse: bool = True,
                max_bases: int = 1 << 26, max_reads: int = 1 << 20, threads: int = 1,
-               want_meta: bool = False) -> _Reader:
+               want_meta: bool = False, want_aux: bool = False) -> _Reader:
     """``samtools fasta -F flag_off`` as an iterator of ReadStream batches."""
     h = c_void_p()
     rc = _native.load().kdf_bam_open(path.encode(), flag_off, 1 if collapse else 0, threads, byref(h))
     _native.check_reader(rc, None)
-    return _Reader(h, max_bases, max_reads, want_meta)
+    return _Reader(h, max_bases, max_reads, want_meta, want_aux)
 
 
 def fasta_reader(path: str, k: int, max_bases: int = 1 << 26, max_reads: int = 1 << 16,

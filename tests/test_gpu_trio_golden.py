@@ -135,3 +135,36 @@ def test_jellyfish_kmer_query_mirror(oracle, discovery):
     assert q.query_batch([]) == set()
     q.close()
     assert len(q._cache) == 0
+
+
+def test_discovery_region_outputs_match_goldens(discovery, tmp_path):
+    """N1: scan hits -> reference coordinates -> clusters -> annotated BED,
+    bedGraph, read-coverage BED and BEDPE, byte for byte equal to the reference's
+    committed outputs (tests/example_output_discovery/giab_discovery.*;
+    flags of tests/conftest.py:99-111: defaults, k=31, min_dk_per_read = 7)."""
+    from kmer_denovo_filter_amd.core.jellyfish_wrappers import _build_proband_jf_index
+    from kmer_denovo_filter_amd.discovery import regions as R
+    gold = os.path.join(GOLDEN, "example_output_discovery")
+    m = json.load(open(os.path.join(gold, "giab_discovery.metrics.json")))
+    jf = _build_proband_jf_index(discovery["proband_fa"], 31, discovery["tmp"], 630)
+    (regions, region_reads, total_inf, region_kmers, unmapped_inf, sv_meta, kcov, rcov) = R._anchor_and_cluster(
+        os.path.join(GIAB, "HG002_child.bam"), None, None, 31, merge_distance=500, threads=4,
+        min_distinct_kmers_per_read=7, proband_jf=jf, n_proband_unique=630)
+    assert total_inf == m["informative_reads"] and unmapped_inf == m["unmapped_informative_reads"]
+    assert len(regions) == m["candidate_regions"] == 21
+    regions = R._filter_regions(regions, region_reads, region_kmers, 1, 1)
+    ann, links = R._annotate_and_link_from_metadata(regions, region_reads, sv_meta)
+    R._classify_regions(regions, ann, links)
+    out = {n: str(tmp_path / n) for n in ("bed", "bedgraph", "readcov", "bedpe")}
+    R._write_bed(regions, region_reads, region_kmers, out["bed"], region_annotations=ann,
+                 filters={"min_distinct_kmers_per_read": 7, "min_supporting_reads": 1, "min_distinct_kmers": 1})
+    R._write_bedgraph(kcov, out["bedgraph"], read_coverage=rcov, min_reads=3)
+    R._write_read_coverage_bed(kcov, rcov, out["readcov"], min_reads=3)
+    R._write_bedpe(links, out["bedpe"])
+    for ours, theirs in (("bed", "giab_discovery.bed"), ("bedgraph", "giab_discovery.kmer_coverage.bedgraph"),
+                         ("readcov", "giab_discovery.read_coverage.bed"), ("bedpe", "giab_discovery.sv.bedpe")):
+        assert open(out[ours]).read() == open(os.path.join(gold, theirs)).read(), theirs
+    for reg, g in zip(regions, m["regions"]):
+        assert (reg[0], reg[1], reg[2]) == (g["chrom"], g["start"], g["end"])
+        assert len(region_reads[reg]) == g["reads"] and len(region_kmers[reg]) == g["unique_kmers"]
+        assert ann[reg]["class"] == g["class"] and ann[reg]["max_clip_len"] == g["max_clip_len"]
