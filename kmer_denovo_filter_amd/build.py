@@ -20,7 +20,8 @@ _SOURCES = [
     ("kdf_sort.hip", ["--offload-arch=gfx950", "-O3"]),
     ("kdf_host.cpp", ["-O2"]),
 ]
-_DEPS = ["kdf_device.h", os.path.join(_INC, "kdf.h")]
+# every header any source includes: a header-only edit must trigger a rebuild
+_DEPS = ["kdf_device.h", "kdf_binned.h", os.path.join(_INC, "kdf.h")]
 
 
 def _newer(target: str, deps) -> bool:

@@ -41,7 +41,8 @@ struct KbPlan {
     uint32_t sub_bits;      // table buckets per partition bucket = 2^sub_bits
     uint32_t log2cap, bucket_bits;
     uint32_t off_stride;    // entries per row of chunk_off = 2^c2 + 1
-    uint32_t dbg;           // experiments only: 1 skip LDS insert, 2 skip gather loads, 4 skip write-back
+    uint32_t dbg;           // experiments only: 1 skip LDS insert, 2 skip gather loads, 4 skip write-back,
+                            // 8 skip A1 copy-out, 16 skip A1 LDS scatter + copy-out
 };
 
 // device scratch shared by the kernels of one pass
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_hist1_kernel(
     for (int i = threadIdx.x; i < nb; i += KB_THREADS) hist[i] = 0;
     __syncthreads();
     const uint64_t slab0 = (uint64_t)blockIdx.x * slabs_per_wg;
+    uint32_t dbg_acc = 0;
     for (uint32_t sl = 0; sl < slabs_per_wg; ++sl) {
         const uint64_t tile = (slab0 + sl) * TILES_PER_SLAB + threadIdx.x / TPT;
         if ((slab0 + sl) * TILES_PER_SLAB >= n_tiles) break;
@@ -155,10 +157,12 @@ __global__ __launch_bounds__(KB_THREADS) void kb_hist1_kernel(
             for (int u = 0; u < WPT; ++u) {
                 if (!((win.valid >> u) & 1)) continue;
                 uint64_t lo, hi; win.key(u, lo, hi);
-                atomicAdd(&hist[kb_coarse(plan, kdf_hash(lo, hi))], 1u);
+                if (plan.dbg & 1024) dbg_acc += atomicAdd(&hist[kb_coarse(plan, kdf_hash(lo, hi))], 1u);   // experiment: returning form
+                else atomicAdd(&hist[kb_coarse(plan, kdf_hash(lo, hi))], 1u);
             }
         }
     }
+    if (dbg_acc == 0x12345678u) s.failed_flag[0] = 2;
     __syncthreads();
     for (int i = threadIdx.x; i < nb; i += KB_THREADS) s.hist_wg[(uint64_t)blockIdx.x * nb + i] = hist[i];
 }
@@ -194,6 +198,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scan1_kernel(KbPlan plan, KbScr
         }
         a[nb] = acc; c[nb] = cacc;
         s.totals[0] = acc; s.totals[1] = cacc; s.totals[2] = 0; s.totals[3] = 0; s.failed_flag[0] = 0;
+        for (int i = 9; i < 16; ++i) s.totals[i] = 0;          // diagnostic stamps
         if (acc) atomicAdd(&ctl->windows[0], acc);
     }
     __syncthreads();
@@ -231,11 +236,25 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
     const uint64_t slab0 = (uint64_t)blockIdx.x * slabs_per_wg;
     const int half = threadIdx.x >> 5, lane32 = threadIdx.x & 31;
     constexpr int NHALF = KB_THREADS / 32;
+    // Four barriers per slab (a 16-wave workgroup alone on its CU pays the skew of
+    // its slowest wave at every barrier): rank | scan by ONE wave | LDS scatter |
+    // copy-out + cursor update.  The next slab's input words are fetched before
+    // the current slab is processed, so waves do not reach the first barrier
+    // skewed by global-load latency.
+    KbWindows<KW> win;
+    if (slab0 * TILES_PER_SLAB < n_tiles)
+        win.load(packed, invalid, slab0 * TILES_PER_SLAB + threadIdx.x / TPT, n_tiles, threadIdx.x % TPT, k);
+    // diagnostic stamps (dbg & 2048 only; never in a timed run): cycles per phase, summed over slabs
+    const bool stamp = (plan.dbg & 2048) && threadIdx.x == 0;
+    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+#define KB_STAMP(i) do { if (stamp) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); tsum[i] += t_ - tprev; tprev = t_; } } while (0)
+    if (stamp) tprev = __builtin_amdgcn_s_memtime();
     for (uint32_t sl = 0; sl < slabs_per_wg; ++sl) {
         if ((slab0 + sl) * TILES_PER_SLAB >= n_tiles) break;          // uniform
-        const uint64_t tile = (slab0 + sl) * TILES_PER_SLAB + threadIdx.x / TPT;
-        KbWindows<KW> win;
-        win.load(packed, invalid, tile, n_tiles, threadIdx.x % TPT, k);
+        KbWindows<KW> nxt;
+        nxt.valid = 0; nxt.k = k; nxt.kmask = win.kmask;
+        if (sl + 1 < slabs_per_wg && (slab0 + sl + 1) * TILES_PER_SLAB < n_tiles)
+            nxt.load(packed, invalid, (slab0 + sl + 1) * TILES_PER_SLAB + threadIdx.x / TPT, n_tiles, threadIdx.x % TPT, k);
         uint64_t klo[WPT], khi[KW == 2 ? WPT : 1];
         uint32_t br[WPT];                       // bin << 16 | rank  (rank < SLAB <= 16384)
         if (win.valid) {
@@ -248,13 +267,44 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
                 br[u] = (bin << 16) | atomicAdd(&hist[bin], 1u);
             }
         }
-        __syncthreads();
-        {
-            const uint32_t v = threadIdx.x < nb ? hist[threadIdx.x] : 0;
-            const uint32_t ex = kb_block_exscan(v, wsum, nullptr);
-            if (threadIdx.x < nb) offs[threadIdx.x] = ex;
+        KB_STAMP(0);                                                    // wave 0: prefetch issue + extract + rank
+        __syncthreads();                                                // B1: all ranks taken
+        KB_STAMP(1);                                                    // wait at B1
+        if (plan.dbg & 128) {                                           // experiment: rank only
+            uint32_t acc = 0;
+#pragma unroll
+            for (int u = 0; u < WPT; ++u) if ((win.valid >> u) & 1) acc += br[u] + (uint32_t)klo[u];
+            if (acc == 0x12345678u) s.failed_flag[0] = 2;
+            for (int i = threadIdx.x; i < nb; i += KB_THREADS) hist[i] = 0;
+            __syncthreads();
+            win = nxt;
+            continue;
         }
-        __syncthreads();
+        if (threadIdx.x < 64) {
+            // exclusive scan of hist[0..nb) by one wave: each lane owns a contiguous strip
+            const int per = (nb + 63) >> 6;                             // 1..16
+            const int b0 = threadIdx.x * per;
+            uint32_t sum = 0;
+            for (int i = 0; i < per; ++i) sum += (b0 + i < nb) ? hist[b0 + i] : 0;
+            uint32_t inc = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if ((int)threadIdx.x >= o) inc += t; }
+            uint32_t run = inc - sum;
+            for (int i = 0; i < per; ++i) if (b0 + i < nb) { offs[b0 + i] = run; run += hist[b0 + i]; }
+        }
+        __syncthreads();                                                // B2: offsets ready
+        KB_STAMP(2);                                                    // scan + B2
+        if (plan.dbg & 256) {                                           // experiment: rank + scan
+            uint32_t acc = 0;
+#pragma unroll
+            for (int u = 0; u < WPT; ++u) if ((win.valid >> u) & 1) acc += offs[br[u] >> 16] + br[u] + (uint32_t)klo[u];
+            if (acc == 0x12345678u) s.failed_flag[0] = 2;
+            __syncthreads();
+            for (int i = threadIdx.x; i < nb; i += KB_THREADS) hist[i] = 0;
+            __syncthreads();
+            win = nxt;
+            continue;
+        }
         if (win.valid) {
 #pragma unroll
             for (int u = 0; u < WPT; ++u) {
@@ -264,23 +314,34 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
                 if constexpr (KW == 2) shi[pos] = khi[u];
             }
         }
-        __syncthreads();
+        __syncthreads();                                                // B3: sorted image complete
+        KB_STAMP(3);                                                    // LDS scatter + B3
+        if (plan.dbg & 512) {                                           // experiment: no copy-out
+            for (int i = threadIdx.x; i < nb; i += KB_THREADS) { gcur[i] += hist[i]; hist[i] = 0; }
+            __syncthreads();
+            win = nxt;
+            continue;
+        }
         for (int bin = half; bin < nb; bin += NHALF) {
             const uint32_t n = hist[bin], o = offs[bin];
             const unsigned long long g = gcur[bin];
             if (g + n > gend[bin]) {           // the stream changed between the passes: never write past the range
                 if (lane32 == 0 && n) s.failed_flag[0] = 1;
-                continue;
+            } else {
+                for (uint32_t i = lane32; i < n; i += 32) {
+                    s.ent_lo[g + i] = slo[o + i];
+                    if constexpr (KW == 2) s.ent_hi[g + i] = shi[o + i];
+                }
             }
-            for (uint32_t i = lane32; i < n; i += 32) {
-                s.ent_lo[g + i] = slo[o + i];
-                if constexpr (KW == 2) s.ent_hi[g + i] = shi[o + i];
-            }
+            if (lane32 == 0) { gcur[bin] = g + n; hist[bin] = 0; }      // this half-wave owns the bin
         }
-        __syncthreads();
-        for (int i = threadIdx.x; i < nb; i += KB_THREADS) { gcur[i] += hist[i]; hist[i] = 0; }
-        __syncthreads();
+        KB_STAMP(4);                                                    // copy-out (wave 0's share)
+        __syncthreads();                                                // B4: hist is zero, image free
+        KB_STAMP(5);                                                    // wait at B4
+        win = nxt;
     }
+    if (stamp) for (int i = 0; i < 6; ++i) atomicAdd(&s.totals[9 + i], tsum[i]);
+#undef KB_STAMP
 }
 
 // B: one workgroup per chunk; in-place sort by fine bin + offset table
@@ -382,8 +443,8 @@ __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
     uint32_t *tcnt = (uint32_t *)(smem + (size_t)B * 8 * KW); // [B]
     uint32_t &sh_failed = tcnt[B], &sh_claimed = tcnt[B + 1];
     uint32_t *wsum = tcnt + B + 2;                            // [32]
-    uint32_t *run_len = wsum + 32;                            // [KB_C_RUNS] entries of this bucket in each chunk
-    unsigned long long *run_first = (unsigned long long *)(run_len + KB_C_RUNS);   // [KB_C_RUNS] (B + 34 + KB_C_RUNS is even: 8-aligned)
+    uint32_t *run_pref = wsum + 32;                           // [KB_C_RUNS] exclusive prefix of run lengths
+    unsigned long long *run_first = (unsigned long long *)(run_pref + KB_C_RUNS);   // [KB_C_RUNS] (B + 34 + KB_C_RUNS is even: 8-aligned)
 
     // `plan` describes the table the partition was built for.  In MODE_REPLAY
     // that is the OLD geometry (the host has grown the table since) and `t` is
@@ -432,116 +493,100 @@ __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
                 first = bstart + (j - j0) * (unsigned long long)CHUNK + r0;
             }
         }
-        if (threadIdx.x < KB_C_RUNS) { run_len[threadIdx.x] = len; run_first[threadIdx.x] = first; }
+        uint32_t total = 0;
+        const uint32_t ex = kb_block_exscan(len, wsum, &total);
+        if (threadIdx.x < KB_C_RUNS) { run_pref[threadIdx.x] = ex; run_first[threadIdx.x] = first; }
         __syncthreads();
         const uint32_t nruns = (uint32_t)((j1 - jb) < (unsigned long long)KB_C_RUNS ? (j1 - jb) : (unsigned long long)KB_C_RUNS);
-        // A wave owns whole runs, RPW at a time: their first 64 entries are loaded
-        // together (RPW loads in flight per lane), then inserted.  Runs average
-        // ~CHUNK / 2^c2 = 64 entries, so most need no tail pass.  No per-entry
-        // search, and all loops here are wave-uniform.
-        constexpr int RPW = 8;
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        constexpr int NWAVES = KB_C_THREADS / 64;
-        for (uint32_t rb = wave * RPW; rb < nruns; rb += NWAVES * RPW) {
-            uint64_t bklo[RPW], bkhi[KW == 2 ? RPW : 1];
-            uint32_t bln[RPW];
+        constexpr int EPB = 16;    // entries per thread per batch: EPB loads in flight per lane
+        // (ei * inv_total) >> 32 ~= ei * nruns / total
+        const unsigned long long inv_total = total ? (((unsigned long long)nruns << 32) / total) : 0;
+        for (uint32_t e0 = 0; e0 < total; e0 += KB_C_THREADS * EPB) {   // wave-uniform trip count
+          uint64_t bklo[EPB], bkhi[KW == 2 ? EPB : 1];
 #pragma unroll
-            for (int q = 0; q < RPW; ++q) {
-                const uint32_t r = rb + q;
-                bln[q] = r < nruns ? run_len[r] : 0;
-                bklo[q] = 0; if constexpr (KW == 2) bkhi[q] = 0;
-                if ((uint32_t)lane < bln[q]) {
-                    const unsigned long long src = run_first[r] + lane;
-                    if (plan.dbg & 2) bklo[q] = (src * 0x9E3779B97F4A7C15ull) >> 2;
-                    else bklo[q] = s.ent_lo[src];
-                    if constexpr (KW == 2) bkhi[q] = s.ent_hi[src];
-                }
+          for (int q = 0; q < EPB; ++q) {
+            const uint32_t ei = e0 + q * KB_C_THREADS + threadIdx.x;
+            bklo[q] = 0; if constexpr (KW == 2) bkhi[q] = 0;
+            if (ei < total) {
+                // largest r with run_pref[r] <= ei.  Runs of a bucket have nearly equal
+                // lengths (hash-uniform), so interpolate and correct by a step or two.
+                uint32_t lo_ = (uint32_t)(((unsigned long long)ei * inv_total) >> 32);
+                if (lo_ >= nruns) lo_ = nruns - 1;
+                while (run_pref[lo_] > ei) --lo_;
+                while (lo_ + 1 < nruns && run_pref[lo_ + 1] <= ei) ++lo_;
+                const unsigned long long src = run_first[lo_] + (ei - run_pref[lo_]);
+                bklo[q] = (plan.dbg & 2) ? ((src * 0x9E3779B97F4A7C15ull) >> 2) : s.ent_lo[src];
+                if constexpr (KW == 2) bkhi[q] = s.ent_hi[src];
             }
-            // pass 0: the RPW prefetched heads; pass 1..: tails of runs longer than 64 (rare)
-            uint32_t maxlen = 0;
+          }
 #pragma unroll
-            for (int q = 0; q < RPW; ++q) maxlen = bln[q] > maxlen ? bln[q] : maxlen;
-            for (uint32_t base_i = 0; base_i < maxlen; base_i += 64) {
-#pragma unroll
-              for (int q = 0; q < RPW; ++q) {
-                if (base_i >= bln[q]) continue;                         // wave-uniform
-                const uint32_t i = base_i + lane;
-                bool todo = i < bln[q];
-                uint64_t klo = bklo[q], khi = KW == 2 ? bkhi[q] : 0;
-                if (base_i) {                                           // tail: load now
-                    klo = 0; khi = 0;
-                    if (todo) {
-                        const unsigned long long src = run_first[rb + q] + i;
-                        klo = s.ent_lo[src];
-                        if constexpr (KW == 2) khi = s.ent_hi[src];
-                    }
-                }
-                const uint64_t h = kdf_hash(klo, khi);
-                const uint64_t home = h >> (64 - plan.log2cap);
-                if (plan.sub_bits && (home >> plan.bucket_bits) != bucket) todo = false;   // sibling bucket's entry
-                if constexpr (MODE == KB_MODE_REPLAY) {
-                    const uint64_t slot = kdf_home(t, h);
-                    bool ok = true;
-                    if constexpr (KW == 1) { if (todo) ok = kdf_add_narrow<true>(t, klo, 1u, slot, t.lo[slot], claimed); }
-                    else ok = kdf_add_wide<true>(t, todo, klo, khi, 1u, slot, claimed);
-                    if (!ok) failed = true;
-                    continue;
-                }
-                if constexpr (KW == 1) {
-                    if (!todo) continue;
-                    if (plan.dbg & 1) { claimed += (uint32_t)(klo >> 61); continue; }
-                    uint32_t sl = (uint32_t)home & bmask;
+          for (int q = 0; q < EPB; ++q) {
+            const uint32_t ei = e0 + q * KB_C_THREADS + threadIdx.x;
+            bool todo = ei < total;
+            const uint64_t klo = bklo[q], khi = KW == 2 ? bkhi[q] : 0;
+            const uint64_t h = kdf_hash(klo, khi);
+            const uint64_t home = h >> (64 - plan.log2cap);
+            if (plan.sub_bits && (home >> plan.bucket_bits) != bucket) todo = false;   // sibling bucket's entry
+            if constexpr (MODE == KB_MODE_REPLAY) {
+                const uint64_t slot = kdf_home(t, h);
+                bool ok = true;
+                if constexpr (KW == 1) { if (todo) ok = kdf_add_narrow<true>(t, klo, 1u, slot, t.lo[slot], claimed); }
+                else ok = kdf_add_wide<true>(t, todo, klo, khi, 1u, slot, claimed);
+                if (!ok) failed = true;
+                continue;
+            }
+            if constexpr (KW == 1) {
+                if (!todo) continue;
+                if (plan.dbg & 1) { claimed += (uint32_t)(klo >> 61); continue; }
+                uint32_t sl = (uint32_t)home & bmask;
+                for (uint32_t n = 0;; ++n) {
+                    if (n > bmask) { failed = true; break; }
                     uint64_t cur = tlo[sl];
-                    if (cur == klo) { atomicAdd(&tcnt[sl], 1u); continue; }      // common case: first probe hits
-                    for (uint32_t n = 0;; ++n) {
-                        if (n > bmask) { failed = true; break; }
-                        if (cur == KDF_EMPTY && MODE == KB_MODE_INSERT) {
-                            cur = atomicCAS((unsigned long long *)&tlo[sl], KDF_EMPTY, klo);
-                            if (cur == KDF_EMPTY) { claimed++; cur = klo; }
-                        }
-                        if (cur == klo) { atomicAdd(&tcnt[sl], 1u); break; }
-                        if (cur == KDF_EMPTY) break;                         // FILTERED: absent
-                        sl = (sl + 1) & bmask;
-                        cur = tlo[sl];
+                    if (cur == KDF_EMPTY && MODE == KB_MODE_INSERT) {
+                        cur = atomicCAS((unsigned long long *)&tlo[sl], KDF_EMPTY, klo);
+                        if (cur == KDF_EMPTY) { claimed++; cur = klo; }
                     }
-                } else {
-                    // wide: claim hi with PENDING, publish lo, then the final hi (all in LDS).
-                    // No lane waits inside a divergent loop (kdf_device.h): a lane that meets
-                    // a PENDING slot retries in the next pass of this wave-uniform loop.
-                    while (__any(todo)) {
-                        if (todo) {
-                            uint32_t sl = (uint32_t)home & bmask;
-                            int res = -1;                                    // -1 probing, 0 done, 1 full, 2 blocked
-                            for (uint32_t n = 0; res < 0; ++n) {
-                                if (n > bmask) { res = 1; break; }
-                                uint64_t chi = __hip_atomic_load(&thi[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                if (chi == KDF_EMPTY && MODE == KB_MODE_INSERT) {
-                                    chi = atomicCAS((unsigned long long *)&thi[sl], KDF_EMPTY, khi | KDF_PENDING);
-                                    if (chi == KDF_EMPTY) {
-                                        __hip_atomic_store(&tlo[sl], klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                        __hip_atomic_store(&thi[sl], khi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                        claimed++;
-                                        atomicAdd(&tcnt[sl], 1u);
-                                        res = 0; break;
-                                    }
-                                }
-                                if (chi == KDF_EMPTY) { res = 0; break; }    // FILTERED: absent
-                                if ((chi & ~KDF_PENDING) == khi) {
-                                    if (chi & KDF_PENDING) { res = 2; break; }
-                                    const uint64_t clo = __hip_atomic_load(&tlo[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    if (clo == klo) { atomicAdd(&tcnt[sl], 1u); res = 0; break; }
-                                }
-                                sl = (sl + 1) & bmask;
-                            }
-                            if (res != 2) { todo = false; if (res == 1) failed = true; }
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                    }
+                    if (cur == klo) { atomicAdd(&tcnt[sl], 1u); break; }
+                    if (cur == KDF_EMPTY) break;                         // FILTERED: absent
+                    sl = (sl + 1) & bmask;
                 }
-              }
+            } else {
+                // wide: claim hi with PENDING, publish lo, then the final hi (all in LDS).
+                // No lane waits inside a divergent loop (kdf_device.h): a lane that meets
+                // a PENDING slot retries in the next pass of this wave-uniform loop.
+                while (__any(todo)) {
+                    if (todo) {
+                        uint32_t sl = (uint32_t)home & bmask;
+                        int res = -1;                                    // -1 probing, 0 done, 1 full, 2 blocked
+                        for (uint32_t n = 0; res < 0; ++n) {
+                            if (n > bmask) { res = 1; break; }
+                            uint64_t chi = __hip_atomic_load(&thi[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (chi == KDF_EMPTY && MODE == KB_MODE_INSERT) {
+                                chi = atomicCAS((unsigned long long *)&thi[sl], KDF_EMPTY, khi | KDF_PENDING);
+                                if (chi == KDF_EMPTY) {
+                                    __hip_atomic_store(&tlo[sl], klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    __hip_atomic_store(&thi[sl], khi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    claimed++;
+                                    atomicAdd(&tcnt[sl], 1u);
+                                    res = 0; break;
+                                }
+                            }
+                            if (chi == KDF_EMPTY) { res = 0; break; }    // FILTERED: absent
+                            if ((chi & ~KDF_PENDING) == khi) {
+                                if (chi & KDF_PENDING) { res = 2; break; }
+                                const uint64_t clo = __hip_atomic_load(&tlo[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (clo == klo) { atomicAdd(&tcnt[sl], 1u); res = 0; break; }
+                            }
+                            sl = (sl + 1) & bmask;
+                        }
+                        if (res != 2) { todo = false; if (res == 1) failed = true; }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
+          }
         }
-        __syncthreads();       // run_len / run_first are rewritten by the next round
+        __syncthreads();       // run_pref / run_first are rewritten by the next round
     }
     if (failed) atomicOr(&sh_failed, 1u);
     if (claimed) atomicAdd(&sh_claimed, claimed);

@@ -251,6 +251,7 @@ struct kdf_engine {
     int opt_force_path = 0;                          // 0 auto, 1 direct, 2 binned
     uint32_t opt_debug_flags = 0;                    // experiments only (KbPlan::dbg)
     uint64_t stat_binned_passes = 0, stat_replayed_buckets = 0;
+    uint64_t stat_dbg[6] = {0, 0, 0, 0, 0, 0};        // diagnostic stamps of the last binned pass
     // optional HIP-event timing of the dominant (stream) kernel
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;   // pending start/stop pairs
@@ -511,7 +512,8 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     if ((rc = kb_reserve(h, 4, (size_t)grid_a * nbins * 4))) return rc;
     if ((rc = kb_reserve(h, 5, (size_t)grid_a * nbins * 4))) return rc;
     s.hist_wg = (uint32_t *)h->kb_buf[4]; s.wg_base = (uint32_t *)h->kb_buf[5];
-    hipLaunchKernelGGL(kb_hist1_kernel<KW>, dim3(grid_a), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
+    if (plan.dbg & 64) (void)hipFuncSetAttribute((const void *)kb_hist1_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, 150000);
+    hipLaunchKernelGGL(kb_hist1_kernel<KW>, dim3(grid_a), dim3(KB_THREADS), (plan.dbg & 64) ? 150000 : 0, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
     hipLaunchKernelGGL(kb_colscan_kernel, dim3(nbins), dim3(256), 0, h->stream, plan, s, (uint32_t)grid_a);
     hipLaunchKernelGGL(kb_scan1_kernel, dim3(1), dim3(KB_THREADS), 0, h->stream, plan, s, (uint32_t)CHUNK, h->ctl);
     HIPCHK(h, hipGetLastError());
@@ -549,11 +551,12 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
         h->prof_tiles.push_back(n_tiles);
         h->prof_stage_ev.push_back(sev);
     }
-    HIPCHK(h, hipMemcpyAsync(h->kb_totals_host, s.totals, 72, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->kb_totals_host, s.totals, 128, hipMemcpyDeviceToHost, h->stream));
     bool full = false;
     if ((rc = ctl_sync(h, &full))) return rc;
     h->stat_binned_passes++;
     h->lazy_empty = false;
+    for (int i = 0; i < 6; ++i) h->stat_dbg[i] = h->kb_totals_host[9 + i];
     if (((unsigned int *)(h->kb_totals_host + 8))[0])
         return fail(h, KDF_ERR_STATE, "binned count: the read stream changed while it was being counted "
                                       "(is another stream still writing it? synchronise before the call)");
@@ -1122,6 +1125,7 @@ int kdf_get_stat(kdf_engine *h, const char *name, int64_t *value) {
     const std::string n(name);
     if (n == "binned_passes") *value = (int64_t)h->stat_binned_passes;
     else if (n == "replayed_buckets") *value = (int64_t)h->stat_replayed_buckets;
+    else if (n.rfind("dbg_t", 0) == 0 && n.size() == 6 && n[5] >= '0' && n[5] <= '5') *value = (int64_t)h->stat_dbg[n[5] - '0'];
     else if (n == "log2cap") *value = h->t.log2cap;
     else if (n == "bucket_bits") *value = h->t.bucket_bits;
     else return fail(h, KDF_ERR_INVALID, "kdf_get_stat: unknown stat %s", name);
