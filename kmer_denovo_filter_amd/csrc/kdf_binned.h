@@ -41,8 +41,7 @@ struct KbPlan {
     uint32_t sub_bits;      // table buckets per partition bucket = 2^sub_bits
     uint32_t log2cap, bucket_bits;
     uint32_t off_stride;    // entries per row of chunk_off = 2^c2 + 1
-    uint32_t dbg;           // experiments only: 1 skip LDS insert, 2 skip gather loads, 4 skip write-back,
-                            // 8 skip A1 copy-out, 16 skip A1 LDS scatter + copy-out
+    uint32_t dbg;           // experiments only (bucket kernel): 1 skip LDS insert, 2 synthetic keys, 4 skip write-back
 };
 
 // device scratch shared by the kernels of one pass
@@ -103,24 +102,38 @@ struct KbWindows {
     int k;
     // The words are pre-shifted once so that window u is taken with COMPILE-TIME
     // shifts (a runtime position would index the word array dynamically).
+    // Two-step load so it can be used as a prefetch: issue() only starts the
+    // global loads (all independent: no load waits on the mask), finish() turns
+    // the raw words into e[] / valid.  The compiler places the vmcnt wait at the
+    // first USE, i.e. in finish().
+    uint64_t raw[NE + 1], m0, m1;
+    int p0_;
+    bool in_range;
+    __device__ __forceinline__ void issue(const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid,
+                                          uint64_t tile, uint64_t n_tiles, int part, int k_) {
+        k = k_; p0_ = part * WPT;
+        kmask = (k >= 32) ? ~0ull : ((1ull << (2 * k)) - 1);
+        in_range = tile < n_tiles;
+        // unconditional loads (a branch around them would make the compiler wait for
+        // them at the join): out-of-range threads read the last tile and are masked
+        // off through in_range in finish()
+        const uint64_t t = in_range ? tile : n_tiles - 1;
+        const uint64_t *src = packed + t * 2 + (p0_ >> 5);
+        m0 = invalid[t]; m1 = invalid[t + 1];
+#pragma unroll
+        for (int i = 0; i <= NE; ++i) raw[i] = src[i];       // within the padded tail (kdf_stream_words)
+    }
+    __device__ __forceinline__ void finish() {
+        const int sh = (p0_ & 31) * 2;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) e[i] = kdf_funnel(raw[i], raw[i + 1], sh);
+        const uint64_t v = kdf_valid_windows(m0, m1, k);
+        valid = in_range ? (uint32_t)((v >> p0_) & ((1ull << WPT) - 1)) : 0u;
+    }
     __device__ __forceinline__ void load(const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid,
                                          uint64_t tile, uint64_t n_tiles, int part, int k_) {
-        k = k_; valid = 0;
-        const int p0 = part * WPT;
-        kmask = (k >= 32) ? ~0ull : ((1ull << (2 * k)) - 1);
-        if (tile < n_tiles) {
-            const uint64_t v = kdf_valid_windows(invalid[tile], invalid[tile + 1], k);
-            valid = (uint32_t)((v >> p0) & ((1ull << WPT) - 1));
-            if (valid) {
-                const uint64_t *src = packed + tile * 2 + (p0 >> 5);
-                const int sh = (p0 & 31) * 2;
-                uint64_t w[NE + 1];
-#pragma unroll
-                for (int i = 0; i <= NE; ++i) w[i] = src[i];     // within the padded tail (kdf_stream_words)
-#pragma unroll
-                for (int i = 0; i < NE; ++i) e[i] = kdf_funnel(w[i], w[i + 1], sh);
-            }
-        }
+        issue(packed, invalid, tile, n_tiles, part, k_);
+        finish();
     }
     __device__ __forceinline__ void key(int u, uint64_t &lo, uint64_t &hi) const {   // u: compile-time
         if constexpr (KW == 1) {
@@ -139,30 +152,26 @@ __global__ __launch_bounds__(KB_THREADS) void kb_hist1_kernel(
     const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid, uint64_t n_tiles, int k,
     KbPlan plan, KbScratch s, uint32_t slabs_per_wg)
 {
-    __shared__ uint32_t hist[1 << KB_C1_MAX];
+    __shared__ uint32_t hist[(1 << KB_C1_MAX) + 1];           // last = dummy counter of invalid windows
     constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT;      // threads per tile
     constexpr uint32_t TILES_PER_SLAB = KB_THREADS / TPT;
     const int nb = 1 << plan.c1;
     for (int i = threadIdx.x; i < nb; i += KB_THREADS) hist[i] = 0;
     __syncthreads();
     const uint64_t slab0 = (uint64_t)blockIdx.x * slabs_per_wg;
-    uint32_t dbg_acc = 0;
     for (uint32_t sl = 0; sl < slabs_per_wg; ++sl) {
         const uint64_t tile = (slab0 + sl) * TILES_PER_SLAB + threadIdx.x / TPT;
         if ((slab0 + sl) * TILES_PER_SLAB >= n_tiles) break;
         KbWindows<KW> win;
         win.load(packed, invalid, tile, n_tiles, threadIdx.x % TPT, k);
-        if (win.valid) {
 #pragma unroll
-            for (int u = 0; u < WPT; ++u) {
-                if (!((win.valid >> u) & 1)) continue;
-                uint64_t lo, hi; win.key(u, lo, hi);
-                if (plan.dbg & 1024) dbg_acc += atomicAdd(&hist[kb_coarse(plan, kdf_hash(lo, hi))], 1u);   // experiment: returning form
-                else atomicAdd(&hist[kb_coarse(plan, kdf_hash(lo, hi))], 1u);
-            }
+        for (int u = 0; u < WPT; ++u) {
+            uint64_t lo, hi; win.key(u, lo, hi);
+            const bool ok = (win.valid >> u) & 1;
+            const uint32_t bin = ok ? kb_coarse(plan, kdf_hash(lo, hi)) : (uint32_t)(1 << KB_C1_MAX);   // dummy counter
+            atomicAdd(&hist[bin], 1u);
         }
     }
-    if (dbg_acc == 0x12345678u) s.failed_flag[0] = 2;
     __syncthreads();
     for (int i = threadIdx.x; i < nb; i += KB_THREADS) s.hist_wg[(uint64_t)blockIdx.x * nb + i] = hist[i];
 }
@@ -210,6 +219,16 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scan1_kernel(KbPlan plan, KbScr
 // layout.  Per slab: rank the windows with LDS atomics, counting-sort them into
 // an LDS image, then copy out run by run (a half-wave per bin) so that every
 // (workgroup, bin) run is one contiguous global write.
+// Barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0),
+// i.e. waits for every outstanding global store; in the persistent scatter
+// kernel (one workgroup per CU) that serialises the copy-out's HBM writes with
+// the next slab's compute.  The barriers there protect LDS data only.
+__device__ __forceinline__ void kb_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 template <int KW>
 __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
     const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid, uint64_t n_tiles, int k,
@@ -218,14 +237,16 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
     constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT, SLAB = KB_THREADS * WPT;
     constexpr uint32_t TILES_PER_SLAB = KB_THREADS / TPT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t *slo = (uint64_t *)smem;                                   // [SLAB]
-    uint64_t *shi = KW == 2 ? slo + SLAB : nullptr;                     // [SLAB] wide
-    unsigned long long *gcur = (unsigned long long *)(smem + (size_t)SLAB * 8 * KW);   // [512] next free entry of this WG per bin
+    uint64_t *slo = (uint64_t *)smem;                                   // [SLAB + 1]: last = trash slot
+    uint64_t *shi = KW == 2 ? slo + (SLAB + 2) : nullptr;               // [SLAB + 1] wide
+    unsigned long long *gcur = (unsigned long long *)(smem + (size_t)(SLAB + 2) * 8 * KW);   // next free entry of this WG per bin
     unsigned long long *gend = gcur + (1 << KB_C1_MAX);                 // [512] end of this WG's range (guard)
-    uint32_t *hist = (uint32_t *)(gend + (1 << KB_C1_MAX));             // [512]
-    uint32_t *offs = hist + (1 << KB_C1_MAX);                           // [512]
-    uint32_t *wsum = offs + (1 << KB_C1_MAX);                           // [32]
+    uint32_t *hist = (uint32_t *)(gend + (1 << KB_C1_MAX));             // [bins + 1]: last = dummy counter of invalid windows
+    uint32_t *offs = hist + (1 << KB_C1_MAX) + 32;                      // [bins + 1]: offs[DUMMY] = trash slot
+    uint32_t *wsum = offs + (1 << KB_C1_MAX) + 32;                      // [32]
+    constexpr int DUMMY = 1 << KB_C1_MAX;
     const int nb = 1 << plan.c1;
+    if (threadIdx.x == 0) { hist[DUMMY] = 0; offs[DUMMY] = (uint32_t)SLAB; }
     for (int i = threadIdx.x; i < nb; i += KB_THREADS) {
         hist[i] = 0;
         const unsigned long long st = s.bin_start[i] + s.wg_base[(uint64_t)blockIdx.x * nb + i];
@@ -244,42 +265,31 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
     KbWindows<KW> win;
     if (slab0 * TILES_PER_SLAB < n_tiles)
         win.load(packed, invalid, slab0 * TILES_PER_SLAB + threadIdx.x / TPT, n_tiles, threadIdx.x % TPT, k);
-    // diagnostic stamps (dbg & 2048 only; never in a timed run): cycles per phase, summed over slabs
-    const bool stamp = (plan.dbg & 2048) && threadIdx.x == 0;
-    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
-#define KB_STAMP(i) do { if (stamp) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); tsum[i] += t_ - tprev; tprev = t_; } } while (0)
-    if (stamp) tprev = __builtin_amdgcn_s_memtime();
     for (uint32_t sl = 0; sl < slabs_per_wg; ++sl) {
         if ((slab0 + sl) * TILES_PER_SLAB >= n_tiles) break;          // uniform
         KbWindows<KW> nxt;
-        nxt.valid = 0; nxt.k = k; nxt.kmask = win.kmask;
-        if (sl + 1 < slabs_per_wg && (slab0 + sl + 1) * TILES_PER_SLAB < n_tiles)
-            nxt.load(packed, invalid, (slab0 + sl + 1) * TILES_PER_SLAB + threadIdx.x / TPT, n_tiles, threadIdx.x % TPT, k);
+        {
+            // prefetch: loads only; (tile >= n_tiles handles "no next slab")
+            const bool more = sl + 1 < slabs_per_wg;
+            nxt.issue(packed, invalid, more ? (slab0 + sl + 1) * TILES_PER_SLAB + threadIdx.x / TPT : n_tiles,
+                      n_tiles, threadIdx.x % TPT, k);
+        }
+        // Branch-free ranking: invalid windows (~4 %) go to a dummy counter
+        // hist[DUMMY], so the WPT returning LDS atomics issue back to back with
+        // ONE wait instead of WPT serialized round trips inside exec branches.
         uint64_t klo[WPT], khi[KW == 2 ? WPT : 1];
         uint32_t br[WPT];                       // bin << 16 | rank  (rank < SLAB <= 16384)
-        if (win.valid) {
 #pragma unroll
-            for (int u = 0; u < WPT; ++u) {
-                if (!((win.valid >> u) & 1)) continue;
-                uint64_t lo, hi; win.key(u, lo, hi);
-                klo[u] = lo; if constexpr (KW == 2) khi[u] = hi;
-                const uint32_t bin = kb_coarse(plan, kdf_hash(lo, hi));
-                br[u] = (bin << 16) | atomicAdd(&hist[bin], 1u);
-            }
+        for (int u = 0; u < WPT; ++u) {
+            uint64_t lo, hi; win.key(u, lo, hi);
+            klo[u] = lo; if constexpr (KW == 2) khi[u] = hi;
+            const bool ok = (win.valid >> u) & 1;
+            const uint32_t bin = ok ? kb_coarse(plan, kdf_hash(lo, hi)) : (uint32_t)DUMMY;
+            br[u] = bin << 16;
         }
-        KB_STAMP(0);                                                    // wave 0: prefetch issue + extract + rank
-        __syncthreads();                                                // B1: all ranks taken
-        KB_STAMP(1);                                                    // wait at B1
-        if (plan.dbg & 128) {                                           // experiment: rank only
-            uint32_t acc = 0;
 #pragma unroll
-            for (int u = 0; u < WPT; ++u) if ((win.valid >> u) & 1) acc += br[u] + (uint32_t)klo[u];
-            if (acc == 0x12345678u) s.failed_flag[0] = 2;
-            for (int i = threadIdx.x; i < nb; i += KB_THREADS) hist[i] = 0;
-            __syncthreads();
-            win = nxt;
-            continue;
-        }
+        for (int u = 0; u < WPT; ++u) br[u] |= atomicAdd(&hist[br[u] >> 16], 1u) & 0xFFFFu;
+        kb_lds_barrier();                                               // B1: all ranks taken
         if (threadIdx.x < 64) {
             // exclusive scan of hist[0..nb) by one wave: each lane owns a contiguous strip
             const int per = (nb + 63) >> 6;                             // 1..16
@@ -292,36 +302,27 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
             uint32_t run = inc - sum;
             for (int i = 0; i < per; ++i) if (b0 + i < nb) { offs[b0 + i] = run; run += hist[b0 + i]; }
         }
-        __syncthreads();                                                // B2: offsets ready
-        KB_STAMP(2);                                                    // scan + B2
-        if (plan.dbg & 256) {                                           // experiment: rank + scan
-            uint32_t acc = 0;
-#pragma unroll
-            for (int u = 0; u < WPT; ++u) if ((win.valid >> u) & 1) acc += offs[br[u] >> 16] + br[u] + (uint32_t)klo[u];
-            if (acc == 0x12345678u) s.failed_flag[0] = 2;
-            __syncthreads();
-            for (int i = threadIdx.x; i < nb; i += KB_THREADS) hist[i] = 0;
-            __syncthreads();
-            win = nxt;
-            continue;
-        }
-        if (win.valid) {
+        kb_lds_barrier();                                               // B2: offsets ready
+        {
+            // invalid windows land on the trash slot (offs[DUMMY] = SLAB, rank masked off)
+            uint32_t pos[WPT];
 #pragma unroll
             for (int u = 0; u < WPT; ++u) {
-                if (!((win.valid >> u) & 1)) continue;
-                const uint32_t pos = offs[br[u] >> 16] + (br[u] & 0xFFFF);
-                slo[pos] = klo[u];
-                if constexpr (KW == 2) shi[pos] = khi[u];
+                const uint32_t bin = br[u] >> 16;
+                pos[u] = offs[bin] + ((bin == (uint32_t)DUMMY) ? 0u : (br[u] & 0xFFFF));
+            }
+#pragma unroll
+            for (int u = 0; u < WPT; ++u) {
+                slo[pos[u]] = klo[u];
+                if constexpr (KW == 2) shi[pos[u]] = khi[u];
             }
         }
-        __syncthreads();                                                // B3: sorted image complete
-        KB_STAMP(3);                                                    // LDS scatter + B3
-        if (plan.dbg & 512) {                                           // experiment: no copy-out
-            for (int i = threadIdx.x; i < nb; i += KB_THREADS) { gcur[i] += hist[i]; hist[i] = 0; }
-            __syncthreads();
-            win = nxt;
-            continue;
-        }
+        // retire the prefetched words of the next slab BEFORE any store is issued:
+        // vmcnt retires in order, so a later wait for these loads would also wait
+        // for every store issued in between
+        nxt.finish();
+        asm volatile("" :: "v"(nxt.e[0]), "v"(nxt.e[1]), "v"(nxt.valid));
+        kb_lds_barrier();                                               // B3: sorted image complete
         for (int bin = half; bin < nb; bin += NHALF) {
             const uint32_t n = hist[bin], o = offs[bin];
             const unsigned long long g = gcur[bin];
@@ -335,13 +336,10 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
             }
             if (lane32 == 0) { gcur[bin] = g + n; hist[bin] = 0; }      // this half-wave owns the bin
         }
-        KB_STAMP(4);                                                    // copy-out (wave 0's share)
-        __syncthreads();                                                // B4: hist is zero, image free
-        KB_STAMP(5);                                                    // wait at B4
+        if (threadIdx.x == 0) hist[DUMMY] = 0;
+        kb_lds_barrier();                                               // B4: hist is zero, image free (stores still draining)
         win = nxt;
     }
-    if (stamp) for (int i = 0; i < 6; ++i) atomicAdd(&s.totals[9 + i], tsum[i]);
-#undef KB_STAMP
 }
 
 // B: one workgroup per chunk; in-place sort by fine bin + offset table

@@ -493,7 +493,7 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     s.failed_flag = (unsigned int *)(s.totals + 8);
     const size_t lds_b = (size_t)CHUNK * 8 * KW + (size_t)(2 * KB_F + 32) * 4 + 16;
     const size_t lds_c = ((size_t)8 * KW + 4) * ((size_t)1 << plan.bucket_bits) + (2 + 32 + KB_C_RUNS) * 4 + (size_t)KB_C_RUNS * 8;
-    const size_t lds_a1 = (size_t)SLAB * 8 * KW + (size_t)nb1 * 16 + (size_t)(2 * nb1 + 32) * 4;
+    const size_t lds_a1 = (size_t)(SLAB + 2) * 8 * KW + (size_t)nb1 * 16 + (size_t)(2 * (nb1 + 32) + 32) * 4;
     int rc = kb_set_lds_attrs<KW>(h, lds_a1, lds_b, lds_c);
     if (rc) return rc;
 
@@ -512,8 +512,7 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     if ((rc = kb_reserve(h, 4, (size_t)grid_a * nbins * 4))) return rc;
     if ((rc = kb_reserve(h, 5, (size_t)grid_a * nbins * 4))) return rc;
     s.hist_wg = (uint32_t *)h->kb_buf[4]; s.wg_base = (uint32_t *)h->kb_buf[5];
-    if (plan.dbg & 64) (void)hipFuncSetAttribute((const void *)kb_hist1_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, 150000);
-    hipLaunchKernelGGL(kb_hist1_kernel<KW>, dim3(grid_a), dim3(KB_THREADS), (plan.dbg & 64) ? 150000 : 0, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
+    hipLaunchKernelGGL(kb_hist1_kernel<KW>, dim3(grid_a), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
     hipLaunchKernelGGL(kb_colscan_kernel, dim3(nbins), dim3(256), 0, h->stream, plan, s, (uint32_t)grid_a);
     hipLaunchKernelGGL(kb_scan1_kernel, dim3(1), dim3(KB_THREADS), 0, h->stream, plan, s, (uint32_t)CHUNK, h->ctl);
     HIPCHK(h, hipGetLastError());

@@ -3,7 +3,7 @@ sys.path.insert(0, '.')
 from kmer_denovo_filter_amd import KmerEngine
 from kmer_denovo_filter_amd.synth import synth_stream
 ds = synth_stream(10_000_000, 150, 100_000_000, seed=20260417, device="cuda:0"); torch.cuda.synchronize()
-for flags in (0, 1024, 1088, 0, 1024, 1088):
+for flags in (0, 0, 0):
     with KmerEngine(31, capacity_hint=1 << 28) as e:
         e.set_option("debug_flags", flags)
         for it in range(3):
