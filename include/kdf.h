@@ -243,6 +243,11 @@ int kdf_reader_last_meta(kdf_reader *r, const uint16_t **flags, const int32_t **
 int kdf_reader_want_aux(kdf_reader *r, int enable);
 int kdf_reader_last_aux(kdf_reader *r, const uint32_t **cigar, const int64_t **cigar_offsets,
                         const char **sa_buf, const int64_t **sa_offsets);
+/* Base qualities (qual[qual_offsets[i] .. qual_offsets[i+1]), 0xFF when the record
+ * has none) and MAPQ of the last batch; needs kdf_reader_want_aux.  Used by the
+ * VCF-mode producer (kmer_utils.py:1037-1172: --min-baseq, vcf/pipeline.py:673: --min-mapq). */
+int kdf_reader_last_quals(kdf_reader *r, const uint8_t **qual, const int64_t **qual_offsets,
+                          const uint8_t **mapq);
 /* Reference sequence names of a BAM reader (header order = ref_id). */
 int kdf_reader_ref_count(kdf_reader *r);
 const char *kdf_reader_ref_name(kdf_reader *r, int i);

@@ -57,6 +57,8 @@ SYMBOLS = [
     ("kdf_reader_want_aux", c_int, [_P, c_int]),
     ("kdf_reader_last_aux", c_int, [_P, POINTER(POINTER(c_uint32)), POINTER(POINTER(c_int64)),
                                     POINTER(c_char_p), POINTER(POINTER(c_int64))]),
+    ("kdf_reader_last_quals", c_int, [_P, POINTER(POINTER(ctypes.c_uint8)), POINTER(POINTER(c_int64)),
+                                      POINTER(POINTER(ctypes.c_uint8))]),
     ("kdf_reader_ref_count", c_int, [_P]),
     ("kdf_reader_ref_name", c_char_p, [_P, c_int]),
     ("kdf_reader_close", None, [_P]),

@@ -131,6 +131,8 @@ struct Record {
     std::vector<uint32_t> cigar;  // BAM encoding: len << 4 | op
     std::string sa;               // SA:Z tag value, empty when absent
     bool has_sa = false;
+    std::vector<uint8_t> qual;    // base qualities (0xFF... when absent)
+    uint8_t mapq = 0;
 };
 
 }  // namespace
@@ -311,6 +313,9 @@ struct kdf_reader {
     std::vector<int64_t> m_cigar_off;   // n_reads + 1
     std::string m_sa;                   // NUL-terminated SA strings, back to back
     std::vector<int64_t> m_sa_off;      // n_reads; -1 = no SA tag
+    std::vector<uint8_t> m_qual;        // base qualities, all records back to back (stream offsets index it minus separators)
+    std::vector<int64_t> m_qual_off;    // n_reads + 1
+    std::vector<uint8_t> m_mapq;        // n_reads
     std::vector<std::string> ref_names;
 };
 
@@ -403,8 +408,11 @@ int bam_next_raw(kdf_reader *r, Record &rec, bool &has_qual) {
     rec.l_seq = l_seq;
     rec.seq4.assign(sq, sq + ((size_t)l_seq + 1) / 2);
     has_qual = l_seq > 0 && sq[((size_t)l_seq + 1) / 2] != 0xFF;
-    rec.cigar.clear(); rec.sa.clear(); rec.has_sa = false;
+    rec.cigar.clear(); rec.sa.clear(); rec.has_sa = false; rec.qual.clear();
+    rec.mapq = p[9];
     if (r->want_aux) {
+        const uint8_t *ql = sq + ((size_t)l_seq + 1) / 2;
+        rec.qual.assign(ql, ql + (size_t)l_seq);
         const uint8_t *cg = p + 32 + l_rn;
         rec.cigar.resize(n_cig);
         for (unsigned i = 0; i < n_cig; ++i) rec.cigar[i] = (uint32_t)le32(cg + 4 * i);
@@ -584,6 +592,7 @@ int kdf_reader_next(kdf_reader *r, uint64_t max_bases, int64_t max_reads, uint64
         return rfail(r, KDF_ERR_INVALID, "kdf_reader_next: bad argument");
     r->m_flags.clear(); r->m_ref.clear(); r->m_pos.clear(); r->m_names.clear(); r->m_name_off.clear();
     r->m_cigar.clear(); r->m_cigar_off.clear(); r->m_sa.clear(); r->m_sa_off.clear();
+    r->m_qual.clear(); r->m_qual_off.clear(); r->m_mapq.clear();
     StreamWriter w(packed_out, invalid_out);
     w.begin(max_bases);
     int64_t n = 0;
@@ -606,6 +615,9 @@ int kdf_reader_next(kdf_reader *r, uint64_t max_bases, int64_t max_reads, uint64
                 r->m_cigar.insert(r->m_cigar.end(), rec.cigar.begin(), rec.cigar.end());
                 if (rec.has_sa) { r->m_sa_off.push_back((int64_t)r->m_sa.size()); r->m_sa.append(rec.sa); r->m_sa.push_back('\0'); }
                 else r->m_sa_off.push_back(-1);
+                r->m_qual_off.push_back((int64_t)r->m_qual.size());
+                r->m_qual.insert(r->m_qual.end(), rec.qual.begin(), rec.qual.end());
+                r->m_mapq.push_back(rec.mapq);
             }
             recycle(r, std::move(rec));
             r->ready.pop_front();
@@ -653,7 +665,7 @@ int kdf_reader_next(kdf_reader *r, uint64_t max_bases, int64_t max_reads, uint64
         }
     }
     if (stream_offsets_out) stream_offsets_out[n] = (int64_t)w.n;
-    if (r->want_aux) r->m_cigar_off.push_back((int64_t)r->m_cigar.size());
+    if (r->want_aux) { r->m_cigar_off.push_back((int64_t)r->m_cigar.size()); r->m_qual_off.push_back((int64_t)r->m_qual.size()); }
     w.finish();
     *n_reads_out = n;
     *n_bases_out = w.n;
@@ -684,6 +696,14 @@ int kdf_reader_last_aux(kdf_reader *r, const uint32_t **cigar, const int64_t **c
     if (cigar_offsets) *cigar_offsets = r->m_cigar_off.data();
     if (sa_buf) *sa_buf = r->m_sa.data();
     if (sa_offsets) *sa_offsets = r->m_sa_off.data();
+    return KDF_OK;
+}
+
+int kdf_reader_last_quals(kdf_reader *r, const uint8_t **qual, const int64_t **qual_offsets, const uint8_t **mapq) {
+    if (!r || !r->want_aux) return KDF_ERR_INVALID;
+    if (qual) *qual = r->m_qual.data();
+    if (qual_offsets) *qual_offsets = r->m_qual_off.data();
+    if (mapq) *mapq = r->m_mapq.data();
     return KDF_OK;
 }
 

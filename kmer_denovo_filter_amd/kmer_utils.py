@@ -34,6 +34,76 @@ def canonicalize(kmer):
     return kmer if kmer < rc else rc
 
 
+def _is_symbolic(allele):
+    """True for VCF alleles without a literal sequence: ``<DEL>``-style, breakends,
+    ``*`` and the empty allele (reference :18-27)."""
+    if not allele:
+        return True
+    return allele[0] == "<" or allele == "*" or "[" in allele or "]" in allele
+
+
+def read_supports_alt(read, variant_pos, ref, alt, min_baseq=0, *, aligned_pairs=None, seq=None, quals=None):
+    """True when the read bases aligned to the reference span of the variant
+    spell exactly *alt* (reference :1037-1101).  A base below *min_baseq* inside
+    the span disqualifies the read; symbolic / missing ALT never match."""
+    if alt is None or _is_symbolic(alt):
+        return False
+    seq = read.query_sequence if seq is None else seq
+    if seq is None:
+        return False
+    if min_baseq > 0 and quals is None:
+        quals = read.query_qualities
+    pairs = read.get_aligned_pairs(matches_only=False) if aligned_pairs is None else aligned_pairs
+    span_end = variant_pos + len(ref)
+    started, bases = False, []
+    for qpos, rpos in pairs:
+        if rpos is not None and rpos >= span_end:
+            break
+        if rpos == variant_pos:
+            started = True
+        if started and qpos is not None:
+            if min_baseq > 0 and quals is not None and quals[qpos] < min_baseq:
+                return False
+            bases.append(seq[qpos])
+    if not started:
+        return False
+    return "".join(bases).upper() == alt.upper()
+
+
+def extract_variant_spanning_kmers(read, variant_pos, k, min_baseq=0, ref=None, alt=None, *,
+                                   aligned_pairs=None, seq=None, quals=None):
+    """Canonical k-mers of the read whose window covers the variant (for an
+    insertion: any of its len(alt) read bases); windows with an N or a base
+    below *min_baseq* are dropped (reference :1104-1172).  The N / quality test
+    looks at the upper-cased read, the k-mer itself keeps the read's case, as
+    in the reference."""
+    try:
+        at = read.get_reference_positions(full_length=True).index(variant_pos)
+    except ValueError:
+        return set()
+    seq = read.query_sequence if seq is None else seq
+    if seq is None:
+        return set()
+    if quals is None:
+        quals = read.query_qualities
+    alt_len = len(alt) if alt and not _is_symbolic(alt) else 1
+    first = max(0, at - k + 1)
+    last = min(len(seq) - k, at + alt_len - 1)
+    if last < first:
+        return set()
+    upper = seq[first:last + k].upper()
+    bad = np.frombuffer(upper.encode(), dtype=np.uint8) == ord("N")
+    if quals is not None and min_baseq > 0:
+        bad = bad | (np.asarray(quals[first:last + k]) < min_baseq)
+    csum = np.concatenate(([0], np.cumsum(bad)))
+    kmers = set()
+    for s0 in range(first, last + 1):
+        o = s0 - first
+        if csum[o + k] - csum[o] == 0:
+            kmers.add(canonicalize(seq[s0:s0 + k]))
+    return kmers
+
+
 def _extract_read_kmers(seq, kmer_size):
     """(canon_at_pos, unique_candidates), reference :91-121: upper-cased read,
     windows holding 'N' skipped, first-seen order."""

@@ -50,6 +50,14 @@ class ReadStream:
     cigar_offsets: Optional[np.ndarray] = None  # int64[n_reads + 1]
     sa_buf: Optional[bytes] = None
     sa_offsets: Optional[np.ndarray] = None   # int64[n_reads], -1 = no SA tag
+    quals: Optional[np.ndarray] = None        # uint8 base qualities, all records back to back
+    qual_offsets: Optional[np.ndarray] = None  # int64[n_reads + 1]
+    mapq: Optional[np.ndarray] = None         # uint8[n_reads]
+
+    def qualities(self, i: int):
+        """uint8 base qualities of record i, or None when the BAM stores none (0xFF)."""
+        q = self.quals[int(self.qual_offsets[i]):int(self.qual_offsets[i + 1])]
+        return None if (len(q) and q[0] == 0xFF) else q
 
     def cigartuples(self, i: int):
         """[(op, length), ...] of record i, as pysam's ``cigartuples``."""
@@ -192,6 +200,13 @@ class _Reader:
                     st.sa_buf = ctypes.string_at(sbase, last + len(ctypes.string_at(sbase + last)) + 1)
                 else:
                     st.sa_buf = b""
+                from ctypes import c_uint8
+                qb, qo, mq = POINTER(c_uint8)(), POINTER(c_int64)(), POINTER(c_uint8)()
+                _native.check_reader(lib.kdf_reader_last_quals(self._h, byref(qb), byref(qo), byref(mq)), self._h)
+                st.qual_offsets = np.ctypeslib.as_array(qo, (n + 1,)).copy()
+                nq = int(st.qual_offsets[-1])
+                st.quals = np.ctypeslib.as_array(qb, (nq,)).copy() if nq else np.zeros(0, np.uint8)
+                st.mapq = np.ctypeslib.as_array(mq, (n,)).copy()
             yield st
         self.close()
 

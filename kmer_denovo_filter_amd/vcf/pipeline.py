@@ -1,0 +1,167 @@
+"""N3: the VCF-mode producer and annotation around the
+engine's parent scan -- mirrors of ``kmer_denovo_filter/vcf/pipeline.py``:
+
+    _parse_vcf_variants     reference :747-810   (plain / gzip VCF text, no pysam)
+    _collect_child_kmers    reference :619-726   (variant-spanning child k-mers -> FASTA)
+    scan_parents            reference :1571-1622 (mother + father count --if, counts ADDED)
+    annotate_variants       reference :1640-1724 (DKU / DKT / DKA, MIN/AVG/MAX_PKC[_ALT])
+
+The reference fetches reads per variant through the BAM index; this reader has no
+index support yet, so the child BAM is read once and reads are matched to the
+variants they overlap (fine for candidate lists; an index would be needed for
+whole-genome VCFs).
+"""
+from __future__ import annotations
+
+import collections
+import gzip
+import logging
+import os
+import statistics
+
+from ..alignment import reads_from_batch
+from ..core.jellyfish_wrappers import _scan_parent_jellyfish
+from ..kmer_utils import _is_symbolic, extract_variant_spanning_kmers, read_supports_alt
+from ..reads import bam_reader
+
+logger = logging.getLogger(__name__)
+
+
+def _select_alt_from_gt(alts, gt):
+    """(alt, non-ref allele indices carried by the genotype); falls back to the
+    first ALT when the genotype carries none."""
+    idx = sorted({i for i in (gt or ()) if i is not None and i > 0 and i <= len(alts)})
+    if idx:
+        return alts[idx[0] - 1], idx
+    return (alts[0] if alts else None), []
+
+
+def _parse_vcf_variants(vcf_path, proband_id=None):
+    """List of dicts chrom / pos (0-based) / ref / alts / alt / id."""
+    opener = gzip.open if vcf_path.endswith(".gz") else open
+    variants, samples = [], []
+    with opener(vcf_path, "rt") as fh:
+        for line in fh:
+            if line.startswith("##"):
+                continue
+            f = line.rstrip("\n").split("\t")
+            if line.startswith("#"):
+                samples = f[9:]
+                continue
+            if len(f) < 5:
+                continue
+            alts = tuple(a for a in f[4].split(",") if a != ".") or None
+            alt = alts[0] if alts else None
+            if alts and len(alts) > 1:
+                if proband_id is not None and proband_id in samples and len(f) > 9:
+                    fmt = f[8].split(":")
+                    sval = f[9 + samples.index(proband_id)].split(":")
+                    gt = None
+                    if "GT" in fmt and fmt.index("GT") < len(sval):
+                        gt = tuple(None if x in (".", "") else int(x)
+                                   for x in sval[fmt.index("GT")].replace("|", "/").split("/"))
+                    alt, _ = _select_alt_from_gt(alts, gt)
+                logger.warning("Multiallelic variant %s:%s; evaluating ALT %s", f[0], f[1], alt)
+            variants.append({"chrom": f[0], "pos": int(f[1]) - 1, "ref": f[3], "alts": alts, "alt": alt,
+                             "id": None if f[2] == "." else f[2]})
+    return variants
+
+
+def _variant_key(var):
+    return f"{var['chrom']}:{var['pos']}:{var['ref']}:{var['alt'] if var['alt'] is not None else '.'}"
+
+
+def _collect_child_kmers(child_bam, ref_fasta, variants, kmer_size, min_baseq, min_mapq, debug_kmers, kmer_fasta,
+                         flush_threshold=500_000):
+    """Variant-spanning child k-mers -> ``kmer_fasta`` (``>{i}\\n{KMER}\\n``, de-duplicated
+    per flush batch).  Returns (total_written, {variant key: [(read name, k-mers, supports_alt)]})."""
+    by_chrom = collections.defaultdict(list)
+    for v in variants:
+        by_chrom[v["chrom"]].append(v)
+    per_variant = {_variant_key(v): [] for v in variants}
+    rd = bam_reader(child_bam, flag_off=0, collapse=False, max_bases=1 << 24, want_aux=True)
+    refs = rd.references()
+    with rd:
+        for batch in rd:
+            keep = [i for i in range(batch.n_reads)
+                    if not (int(batch.flags[i]) & (0x4 | 0x100 | 0x800 | 0x400))
+                    and int(batch.mapq[i]) >= min_mapq
+                    and 0 <= int(batch.ref_ids[i]) < len(refs) and refs[int(batch.ref_ids[i])] in by_chrom]
+            for read in reads_from_batch(batch, refs, keep):
+                rstart, rend = read.reference_start, read.reference_end
+                pairs = None
+                for var in by_chrom[read.reference_name]:
+                    pos = var["pos"]
+                    if not (rstart <= pos < rend):
+                        continue
+                    if var["alt"] is not None and _is_symbolic(var["alt"]):
+                        continue
+                    kmers = extract_variant_spanning_kmers(read, pos, kmer_size, min_baseq, ref=var["ref"],
+                                                           alt=var["alt"], seq=read.query_sequence,
+                                                           quals=read.query_qualities)
+                    if not kmers:
+                        continue
+                    if pairs is None:
+                        pairs = read.get_aligned_pairs(matches_only=False)
+                    supports = read_supports_alt(read, pos, var["ref"], var["alt"], min_baseq=min_baseq,
+                                                 aligned_pairs=pairs, seq=read.query_sequence,
+                                                 quals=read.query_qualities)
+                    per_variant[_variant_key(var)].append((read.query_name, kmers, supports))
+    total_written = 0
+    batch_set = set()
+    with open(kmer_fasta, "w") as fh:
+        def flush():
+            nonlocal total_written
+            for km in batch_set:
+                fh.write(f">{total_written}\n{km}\n")
+                total_written += 1
+            batch_set.clear()
+        for var in variants:                       # variant order, as the reference writes them
+            for _name, kmers, _s in per_variant[_variant_key(var)]:
+                batch_set.update(kmers)
+                if len(batch_set) >= flush_threshold:
+                    flush()
+        if batch_set:
+            flush()
+    return total_written, per_variant
+
+
+def scan_parents(mother_bam, father_bam, ref_fasta, kmer_fasta, kmer_size, tmpdir, threads, total_child_kmers):
+    """Step 3: both parents are scanned for the child k-mers with the engine and
+    their counts are ADDED (Counter.update, reference :1592,1609)."""
+    found = collections.Counter()
+    for label, bam in (("mother", mother_bam), ("father", father_bam)):
+        found.update(_scan_parent_jellyfish(bam, ref_fasta, kmer_fasta, kmer_size, os.path.join(tmpdir, label),
+                                            threads, n_filter_kmers=total_child_kmers))
+    return found
+
+
+def annotate_variants(variants, variant_read_kmers, parent_found_kmers):
+    """Step 4: per-variant evidence (reference :1662-1724)."""
+    parent_set = set(parent_found_kmers)
+    out = {}
+    for var in variants:
+        key = _variant_key(var)
+        spanning, informative, informative_alt = set(), set(), set()
+        all_kmers, alt_kmers = set(), set()
+        for name, kmers, supports_alt in variant_read_kmers.get(key, []):
+            spanning.add(name)
+            all_kmers.update(kmers)
+            if supports_alt:
+                alt_kmers.update(kmers)
+            if not kmers.issubset(parent_set):
+                informative.add(name)
+                if supports_alt:
+                    informative_alt.add(name)
+        dkt, dku, dka = len(spanning), len(informative), len(informative_alt)
+
+        def pkc(ks):
+            c = [parent_found_kmers[x] for x in ks if x in parent_set]
+            return (max(c), round(statistics.mean(c), 2), min(c)) if c else (0, 0.0, 0)
+        mx, av, mn = pkc(all_kmers)
+        mxa, ava, mna = pkc(alt_kmers)
+        out[key] = {"dku": dku, "dkt": dkt, "dka": dka,
+                    "dku_dkt": round(dku / dkt, 4) if dkt else 0.0, "dka_dkt": round(dka / dkt, 4) if dkt else 0.0,
+                    "max_pkc": mx, "avg_pkc": av, "min_pkc": mn,
+                    "max_pkc_alt": mxa, "avg_pkc_alt": ava, "min_pkc_alt": mna}
+    return out

@@ -168,3 +168,43 @@ def test_discovery_region_outputs_match_goldens(discovery, tmp_path):
         assert (reg[0], reg[1], reg[2]) == (g["chrom"], g["start"], g["end"])
         assert len(region_reads[reg]) == g["reads"] and len(region_kmers[reg]) == g["unique_kmers"]
         assert ann[reg]["class"] == g["class"] and ann[reg]["max_clip_len"] == g["max_clip_len"]
+
+
+def test_vcf_mode_goldens(tmp_path):
+    """N3: VCF mode end to end on the engine (tests/conftest.py:53-64: defaults
+    k=31, --min-baseq 20, --min-mapq 20).  Pins the count --if COUNT VALUES
+    (summed over the parents) through MIN/AVG/MAX_PKC[_ALT] of all 22 variants
+    against the reference's committed summary (tests/example_output/summary.txt:31-52)
+    and metrics.json (1484 / 1294 / 190 / 12)."""
+    from kmer_denovo_filter_amd.vcf.pipeline import (_collect_child_kmers, _parse_vcf_variants, annotate_variants,
+                                                     scan_parents)
+    gold = os.path.join(GOLDEN, "example_output")
+    m = json.load(open(os.path.join(gold, "metrics.json")))
+    variants = _parse_vcf_variants(os.path.join(GIAB, "candidates.vcf.gz"), proband_id="HG002")
+    assert len(variants) == m["total_variants"] == 22
+    fa = str(tmp_path / "child_kmers.fa")
+    total, per_variant = _collect_child_kmers(os.path.join(GIAB, "HG002_child.bam"), None, variants, 31, 20, 20,
+                                              False, fa)
+    assert total == m["total_child_kmers"] == 1484
+    found = scan_parents(os.path.join(GIAB, "HG004_mother.bam"), os.path.join(GIAB, "HG003_father.bam"), None, fa,
+                         31, str(tmp_path), 4, total)
+    assert len(found) == m["parent_found_kmers"] == 1294
+    assert max(0, total - len(found)) == m["child_unique_kmers"] == 190
+    ann = annotate_variants(variants, per_variant, found)
+    assert sum(1 for a in ann.values() if a["dku"] > 0) == m["variants_with_unique_reads"] == 12
+    rows = {}
+    for line in open(os.path.join(gold, "summary.txt")):
+        f = line.split()
+        if len(f) == 14 and f[0].startswith("chr") and ">" in f[1]:
+            chrom, pos = f[0].split(":")
+            ref, alt = f[1].split(">")
+            rows[f"{chrom}:{int(pos) - 1}:{ref}:{alt}"] = f[2:13]
+    assert len(rows) == 22
+    for key, g in rows.items():
+        a = ann[key]
+        got = [a["dku"], a["dkt"], a["dka"], a["dku_dkt"], a["dka_dkt"], a["max_pkc"], a["avg_pkc"], a["min_pkc"],
+               a["max_pkc_alt"], a["avg_pkc_alt"], a["min_pkc_alt"]]
+        exp = [int(g[0]), int(g[1]), int(g[2]), float(g[3]), float(g[4]), int(g[5]), float(g[6]), int(g[7]),
+               int(g[8]), float(g[9]), int(g[10])]
+        assert got == exp, (key, got, exp)
+    assert ann["chr19:15018719:G:A"]["max_pkc"] == 2177 and ann["chr18:62805215:A:ATAATATACACTGCATAGGTTATACATATACAGTG"]["avg_pkc"] == 683.58
