@@ -248,11 +248,26 @@ int kdf_reader_last_aux(kdf_reader *r, const uint32_t **cigar, const int64_t **c
  * VCF-mode producer (kmer_utils.py:1037-1172: --min-baseq, vcf/pipeline.py:673: --min-mapq). */
 int kdf_reader_last_quals(kdf_reader *r, const uint8_t **qual, const int64_t **qual_offsets,
                           const uint8_t **mapq);
+/* Record number in the file (0-based, counted before the flag filter) of every read
+ * of the last batch: the handle kdf_bam_write_subset takes. */
+int kdf_reader_last_ordinals(kdf_reader *r, const uint64_t **ordinals);
 /* Reference sequence names of a BAM reader (header order = ref_id). */
 int kdf_reader_ref_count(kdf_reader *r);
 const char *kdf_reader_ref_name(kdf_reader *r, int i);
 void kdf_reader_close(kdf_reader *r);
 const char *kdf_reader_error(const kdf_reader *r);
+
+/* N4: the informative-reads BAM (discovery/pipeline.py:1979-2079 `_write_informative_reads_discovery`,
+ * vcf/pipeline.py:1307-1357 `_write_informative_reads`: pysam write + `samtools sort` + `samtools index`).
+ * Copies the records ordinals[0..n) (strictly ascending file record numbers, see
+ * kdf_reader_last_ordinals) of src_bam to dst_bam byte for byte, appending
+ * aux[aux_offsets[i] .. aux_offsets[i+1]) -- optional fields in BAM encoding, e.g.
+ * "dkC\x01" or "DVZchr1:5:A:T\0" -- to record i (aux may be NULL).  With sort_and_index
+ * the records are coordinate sorted (samtools order: tid unsigned, pos, strand; stable),
+ * the header gets @HD SO:coordinate and dst_bam + ".bai" is written (SAM spec 5.2). */
+int kdf_bam_write_subset(const char *src_bam, const char *dst_bam, const uint64_t *ordinals, uint64_t n,
+                         const uint8_t *aux, const uint64_t *aux_offsets, int sort_and_index, int threads,
+                         uint64_t *n_written);
 
 #ifdef __cplusplus
 }

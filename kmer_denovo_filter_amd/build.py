@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_PKG, "libkdf.so")
 _SOURCES = [
     ("kdf_engine.hip", ["--offload-arch=gfx950", "-O3"]),
     ("kdf_sort.hip", ["--offload-arch=gfx950", "-O3"]),
-    ("kdf_host.cpp", ["-O2"]),
+    ("kdf_host.cpp", ["-O2", "-x", "c++"]),          # host only: no device pass
 ]
 # every header any source includes: a header-only edit must trigger a rebuild
 _DEPS = ["kdf_device.h", "kdf_binned.h", os.path.join(_INC, "kdf.h")]

@@ -12,7 +12,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <deque>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -133,6 +135,7 @@ struct Record {
     bool has_sa = false;
     std::vector<uint8_t> qual;    // base qualities (0xFF... when absent)
     uint8_t mapq = 0;
+    uint64_t ordinal = 0;         // 0-based record number in the file (before any flag filter)
 };
 
 }  // namespace
@@ -316,6 +319,13 @@ struct kdf_reader {
     std::vector<uint8_t> m_qual;        // base qualities, all records back to back (stream offsets index it minus separators)
     std::vector<int64_t> m_qual_off;    // n_reads + 1
     std::vector<uint8_t> m_mapq;        // n_reads
+    std::vector<uint64_t> m_ordinal;    // n_reads: record number in the file
+    uint64_t n_records = 0;             // raw records parsed so far
+    std::vector<uint8_t> header_raw;    // magic .. end of the reference list, as in the file
+    std::vector<int32_t> ref_lens;
+    bool no_compact = false;            // while the header is being read (header_raw is cut from inbuf)
+    const uint8_t *last_raw = nullptr;  // the record bam_next_raw just parsed (valid until the next call)
+    size_t last_raw_len = 0;
     std::vector<std::string> ref_names;
 };
 
@@ -333,7 +343,7 @@ int rfail(kdf_reader *r, int code, const char *fmt, ...) {
 // read + inflate the next BGZF block, append to r->inbuf.  returns 0 ok, 1 eof, <0 error
 int bgzf_read_block(kdf_reader *r) {
     // compact the consumed prefix now and then
-    if (r->inpos > (1u << 20) && r->inpos * 2 > r->inbuf.size()) {
+    if (!r->no_compact && r->inpos > (1u << 20) && r->inpos * 2 > r->inbuf.size()) {
         r->inbuf.erase(r->inbuf.begin(), r->inbuf.begin() + r->inpos);
         r->inpos = 0;
     }
@@ -368,11 +378,13 @@ inline int32_t le32(const uint8_t *p) { return (int32_t)(p[0] | (p[1] << 8) | (p
 
 int bam_read_header(kdf_reader *r) {
     bool e;
+    r->no_compact = true;
     if (!bam_need(r, 12, &e)) { std::string m = e ? r->err : std::string("empty or truncated BAM"); return rfail(r, KDF_ERR_IO, "%s", m.c_str()); }
     const uint8_t *p = r->inbuf.data() + r->inpos;
     if (memcmp(p, "BAM\1", 4) != 0) return rfail(r, KDF_ERR_IO, "not a BAM file (bad magic)");
     const int32_t l_text = le32(p + 4);
     if (!bam_need(r, 12 + (size_t)l_text, &e)) return rfail(r, KDF_ERR_IO, "truncated BAM header");
+    const size_t h0 = r->inpos;
     r->inpos += 8 + (size_t)l_text;
     p = r->inbuf.data() + r->inpos;
     const int32_t n_ref = le32(p);
@@ -382,8 +394,11 @@ int bam_read_header(kdf_reader *r) {
         const int32_t l_name = le32(r->inbuf.data() + r->inpos);
         if (!bam_need(r, 8 + (size_t)l_name, &e)) return rfail(r, KDF_ERR_IO, "truncated BAM reference list");
         r->ref_names.emplace_back((const char *)r->inbuf.data() + r->inpos + 4, l_name > 0 ? (size_t)l_name - 1 : 0);
+        r->ref_lens.push_back(le32(r->inbuf.data() + r->inpos + 4 + (size_t)l_name));
         r->inpos += 8 + (size_t)l_name;
     }
+    r->header_raw.assign(r->inbuf.begin() + (long)h0, r->inbuf.begin() + (long)r->inpos);
+    r->no_compact = false;
     return KDF_OK;
 }
 
@@ -410,6 +425,8 @@ int bam_next_raw(kdf_reader *r, Record &rec, bool &has_qual) {
     has_qual = l_seq > 0 && sq[((size_t)l_seq + 1) / 2] != 0xFF;
     rec.cigar.clear(); rec.sa.clear(); rec.has_sa = false; rec.qual.clear();
     rec.mapq = p[9];
+    rec.ordinal = r->n_records++;
+    r->last_raw = p; r->last_raw_len = (size_t)bs;
     if (r->want_aux) {
         const uint8_t *ql = sq + ((size_t)l_seq + 1) / 2;
         rec.qual.assign(ql, ql + (size_t)l_seq);
@@ -592,7 +609,7 @@ int kdf_reader_next(kdf_reader *r, uint64_t max_bases, int64_t max_reads, uint64
         return rfail(r, KDF_ERR_INVALID, "kdf_reader_next: bad argument");
     r->m_flags.clear(); r->m_ref.clear(); r->m_pos.clear(); r->m_names.clear(); r->m_name_off.clear();
     r->m_cigar.clear(); r->m_cigar_off.clear(); r->m_sa.clear(); r->m_sa_off.clear();
-    r->m_qual.clear(); r->m_qual_off.clear(); r->m_mapq.clear();
+    r->m_qual.clear(); r->m_qual_off.clear(); r->m_mapq.clear(); r->m_ordinal.clear();
     StreamWriter w(packed_out, invalid_out);
     w.begin(max_bases);
     int64_t n = 0;
@@ -610,6 +627,7 @@ int kdf_reader_next(kdf_reader *r, uint64_t max_bases, int64_t max_reads, uint64
             r->m_flags.push_back(rec.flag); r->m_ref.push_back(rec.ref_id); r->m_pos.push_back(rec.pos);
             r->m_name_off.push_back((int64_t)r->m_names.size());
             r->m_names.append(rec.name); r->m_names.push_back('\0');
+            r->m_ordinal.push_back(rec.ordinal);
             if (r->want_aux) {
                 r->m_cigar_off.push_back((int64_t)r->m_cigar.size());
                 r->m_cigar.insert(r->m_cigar.end(), rec.cigar.begin(), rec.cigar.end());
@@ -707,11 +725,235 @@ int kdf_reader_last_quals(kdf_reader *r, const uint8_t **qual, const int64_t **q
     return KDF_OK;
 }
 
+int kdf_reader_last_ordinals(kdf_reader *r, const uint64_t **ordinals) {
+    if (!r || r->kind != kdf_reader::BAM || !ordinals) return KDF_ERR_INVALID;
+    *ordinals = r->m_ordinal.data();
+    return KDF_OK;
+}
+
 int kdf_reader_ref_count(kdf_reader *r) { return r ? (int)r->ref_names.size() : -1; }
 
 const char *kdf_reader_ref_name(kdf_reader *r, int i) {
     if (!r || i < 0 || i >= (int)r->ref_names.size()) return nullptr;
     return r->ref_names[(size_t)i].c_str();
+}
+
+}  // extern "C"
+
+// ---- N4: subset BAM writer (BGZF + coordinate sort + BAI) ----------------------
+
+namespace {
+
+struct BgzfWriter {
+    FILE *fp = nullptr;
+    std::vector<uint8_t> buf;            // pending uncompressed bytes (< BLOCK)
+    std::vector<uint8_t> comp;
+    uint64_t coff = 0;                   // compressed offset of the block `buf` will become
+    bool failed = false;
+    static constexpr size_t BLOCK = 0xff00;
+    uint64_t tell() const { return (coff << 16) | (uint64_t)buf.size(); }
+    void flush_block() {
+        comp.resize(BLOCK + 1024);
+        z_stream zs; memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { failed = true; return; }
+        zs.next_in = buf.data(); zs.avail_in = (uInt)buf.size();
+        zs.next_out = comp.data() + 18; zs.avail_out = (uInt)(comp.size() - 18 - 8);
+        const int zr = deflate(&zs, Z_FINISH);
+        const size_t clen = zs.total_out;
+        deflateEnd(&zs);
+        if (zr != Z_STREAM_END) { failed = true; return; }
+        const size_t bsize = 18 + clen + 8;                       // always < 65536 for <= 0xff00 input bytes
+        static const uint8_t h[12] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0};
+        memcpy(comp.data(), h, 12);
+        comp[12] = 'B'; comp[13] = 'C'; comp[14] = 2; comp[15] = 0;
+        comp[16] = (uint8_t)((bsize - 1) & 0xff); comp[17] = (uint8_t)((bsize - 1) >> 8);
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), buf.data(), (uInt)buf.size());
+        const uint32_t isz = (uint32_t)buf.size();
+        uint8_t *t = comp.data() + 18 + clen;
+        for (int i = 0; i < 4; ++i) { t[i] = (uint8_t)(crc >> (8 * i)); t[4 + i] = (uint8_t)(isz >> (8 * i)); }
+        if (fwrite(comp.data(), 1, bsize, fp) != bsize) failed = true;
+        coff += bsize;
+        buf.clear();
+    }
+    void write(const uint8_t *p, size_t n) {
+        while (n) {
+            const size_t take = std::min(n, BLOCK - buf.size());
+            buf.insert(buf.end(), p, p + take);
+            p += take; n -= take;
+            if (buf.size() == BLOCK) flush_block();
+        }
+    }
+    void finish() {
+        if (!buf.empty()) flush_block();
+        flush_block();                                            // empty block = the BGZF EOF marker
+    }
+};
+
+inline int reg2bin(int64_t beg, int64_t end) {                    // SAM spec section 5.3
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+inline void put32(std::vector<uint8_t> &v, uint32_t x) { for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
+inline void put64(std::vector<uint8_t> &v, uint64_t x) { for (int i = 0; i < 8; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
+
+struct RefIndex {
+    std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins;
+    std::vector<uint64_t> linear;
+    uint64_t off_beg = 0, off_end = 0, n_mapped = 0, n_unmapped = 0;
+    bool any = false;
+};
+
+// header text with @HD ... SO:coordinate (what `samtools sort` leaves, reference :2069)
+std::string sorted_header_text(const std::string &text) {
+    std::string out;
+    size_t eol = text.find('\n');
+    std::string first = text.substr(0, eol == std::string::npos ? text.size() : eol);
+    if (first.compare(0, 3, "@HD") == 0) {
+        std::string hd;
+        size_t a = 0;
+        bool had_so = false;
+        while (a <= first.size()) {
+            size_t b = first.find('\t', a);
+            if (b == std::string::npos) b = first.size();
+            std::string f = first.substr(a, b - a);
+            if (f.compare(0, 3, "SO:") == 0) { f = "SO:coordinate"; had_so = true; }
+            if (f.compare(0, 3, "GO:") != 0) { if (!hd.empty()) hd += '\t'; hd += f; }
+            a = b + 1;
+        }
+        if (!had_so) hd += "\tSO:coordinate";
+        out = hd + "\n" + (eol == std::string::npos ? std::string() : text.substr(eol + 1));
+    } else {
+        out = "@HD\tVN:1.6\tSO:coordinate\n" + text;
+    }
+    return out;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kdf_bam_write_subset(const char *src_bam, const char *dst_bam, const uint64_t *ordinals, uint64_t n,
+                         const uint8_t *aux, const uint64_t *aux_offsets, int sort_and_index, int threads,
+                         uint64_t *n_written) {
+    if (!src_bam || !dst_bam || (n && !ordinals) || (aux && !aux_offsets))
+        return rfail(nullptr, KDF_ERR_INVALID, "kdf_bam_write_subset: bad argument");
+    for (uint64_t i = 1; i < n; ++i)
+        if (ordinals[i] <= ordinals[i - 1]) return rfail(nullptr, KDF_ERR_INVALID, "kdf_bam_write_subset: ordinals must be strictly ascending");
+    kdf_reader *r = nullptr;
+    int rc = kdf_bam_open(src_bam, 0, 0, threads, &r);
+    if (rc) return rc;
+    struct Rec { std::vector<uint8_t> raw; uint64_t key_hi, key_lo; };
+    std::vector<Rec> recs;
+    recs.reserve((size_t)n);
+    {
+        Record scratch; bool hq;
+        uint64_t want = 0;
+        while (want < n) {
+            const int pr = bam_next_raw(r, scratch, hq);
+            if (pr < 0) { g_host_err = r->err; kdf_reader_close(r); return KDF_ERR_IO; }
+            if (pr == 1) break;
+            if (scratch.ordinal != ordinals[want]) continue;
+            Rec x;
+            x.raw.assign(r->last_raw, r->last_raw + r->last_raw_len);
+            if (aux) x.raw.insert(x.raw.end(), aux + aux_offsets[want], aux + aux_offsets[want + 1]);
+            // samtools sort order: tid as unsigned (unplaced last), pos + 1, reverse strand; stable
+            x.key_hi = (uint64_t)(uint32_t)scratch.ref_id;
+            x.key_lo = ((uint64_t)(uint32_t)(scratch.pos + 1) << 1) | ((scratch.flag & 0x10) ? 1u : 0u);
+            recs.push_back(std::move(x));
+            ++want;
+        }
+        if (want < n) { kdf_reader_close(r); return rfail(nullptr, KDF_ERR_INVALID, "kdf_bam_write_subset: record %llu is past the end of %s", (unsigned long long)ordinals[want], src_bam); }
+    }
+    std::vector<uint8_t> header = r->header_raw;
+    const std::vector<int32_t> ref_lens = r->ref_lens;
+    kdf_reader_close(r);
+    if (sort_and_index) {
+        std::stable_sort(recs.begin(), recs.end(), [](const Rec &a, const Rec &b) {
+            return a.key_hi != b.key_hi ? a.key_hi < b.key_hi : a.key_lo < b.key_lo; });
+        const int32_t l_text = le32(header.data() + 4);
+        const std::string text = sorted_header_text(std::string((const char *)header.data() + 8, (size_t)l_text));
+        std::vector<uint8_t> h2(header.begin(), header.begin() + 4);
+        put32(h2, (uint32_t)text.size());
+        h2.insert(h2.end(), text.begin(), text.end());
+        h2.insert(h2.end(), header.begin() + 8 + l_text, header.end());
+        header.swap(h2);
+    }
+    BgzfWriter w;
+    w.fp = fopen(dst_bam, "wb");
+    if (!w.fp) return rfail(nullptr, KDF_ERR_IO, "cannot create %s", dst_bam);
+    w.write(header.data(), header.size());
+    w.flush_block();                                             // records start on a block boundary, as htslib writes them
+    std::vector<RefIndex> idx(ref_lens.size());
+    uint64_t n_no_coor = 0;
+    for (auto &x : recs) {
+        // keep a record inside one block when it fits (htslib does the same)
+        if (w.buf.size() + 4 + x.raw.size() > BgzfWriter::BLOCK && !w.buf.empty()) w.flush_block();
+        const uint64_t vo0 = w.tell();
+        uint8_t bs[4]; const uint32_t l = (uint32_t)x.raw.size();
+        for (int i = 0; i < 4; ++i) bs[i] = (uint8_t)(l >> (8 * i));
+        const uint8_t *p = x.raw.data();
+        const int32_t tid = le32(p), pos = le32(p + 4);
+        const unsigned l_rn = p[8], n_cig = p[12] | (p[13] << 8);
+        const uint16_t flag = (uint16_t)(p[14] | (p[15] << 8));
+        int64_t rlen = 0;
+        for (unsigned i = 0; i < n_cig; ++i) {
+            const uint32_t c = (uint32_t)le32(p + 32 + l_rn + 4 * i);
+            const unsigned op = c & 15;
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += c >> 4;
+        }
+        const int64_t beg = pos, end = pos + ((flag & 4) || rlen == 0 ? 1 : rlen);
+        const int bin = tid >= 0 && pos >= 0 ? reg2bin(beg, end) : 4680;
+        x.raw[10] = (uint8_t)(bin & 0xff); x.raw[11] = (uint8_t)(bin >> 8);
+        w.write(bs, 4);
+        w.write(x.raw.data(), x.raw.size());
+        const uint64_t vo1 = w.tell();
+        if (!sort_and_index) continue;
+        if (tid < 0 || (size_t)tid >= idx.size() || pos < 0) { ++n_no_coor; continue; }
+        RefIndex &ri = idx[(size_t)tid];
+        auto &ch = ri.bins[(uint32_t)bin];
+        if (!ch.empty() && ch.back().second == vo0) ch.back().second = vo1; else ch.emplace_back(vo0, vo1);
+        const size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
+        if (ri.linear.size() <= w1) ri.linear.resize(w1 + 1, 0);
+        for (size_t k = w0; k <= w1; ++k) if (ri.linear[k] == 0) ri.linear[k] = vo0;
+        if (!ri.any) { ri.off_beg = vo0; ri.any = true; }
+        ri.off_end = vo1;
+        if (flag & 4) ++ri.n_unmapped; else ++ri.n_mapped;
+    }
+    w.finish();
+    const bool wfail = w.failed || fclose(w.fp) != 0;
+    if (wfail) return rfail(nullptr, KDF_ERR_IO, "write to %s failed", dst_bam);
+    if (sort_and_index) {
+        std::vector<uint8_t> b = {'B', 'A', 'I', 1};
+        put32(b, (uint32_t)idx.size());
+        for (auto &ri : idx) {
+            put32(b, (uint32_t)(ri.bins.size() + (ri.any ? 1 : 0)));
+            for (auto &kv : ri.bins) {
+                put32(b, kv.first); put32(b, (uint32_t)kv.second.size());
+                for (auto &c : kv.second) { put64(b, c.first); put64(b, c.second); }
+            }
+            if (ri.any) {                                          // samtools' metadata pseudo-bin
+                put32(b, 37450); put32(b, 2);
+                put64(b, ri.off_beg); put64(b, ri.off_end); put64(b, ri.n_mapped); put64(b, ri.n_unmapped);
+            }
+            // an empty 16 kb window takes the offset of the next filled one (htslib fills backwards)
+            for (size_t k = ri.linear.size(); k-- > 1;) if (ri.linear[k - 1] == 0) ri.linear[k - 1] = ri.linear[k];
+            put32(b, (uint32_t)ri.linear.size());
+            for (uint64_t v : ri.linear) put64(b, v);
+        }
+        put64(b, n_no_coor);
+        const std::string bai = std::string(dst_bam) + ".bai";
+        FILE *fi = fopen(bai.c_str(), "wb");
+        if (!fi || fwrite(b.data(), 1, b.size(), fi) != b.size() || fclose(fi) != 0)
+            return rfail(nullptr, KDF_ERR_IO, "cannot write %s", bai.c_str());
+    }
+    if (n_written) *n_written = (uint64_t)recs.size();
+    return KDF_OK;
 }
 
 }  // extern "C"

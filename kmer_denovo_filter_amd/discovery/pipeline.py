@@ -169,3 +169,37 @@ def _filter_parents_discovery(mother_bam, father_bam, ref_fasta, child_non_ref_f
     logger.info("Proband-unique k-mers (absent from both parents): %d / %d", n_proband, n_input)
     logger.info("Proband-unique FASTA: %s (%s)", proband_unique_fa, _format_file_size(proband_unique_fa))
     return n_proband, proband_unique_fa
+
+
+def _write_informative_reads_discovery(child_bam, ref_fasta, proband_unique_kmers_or_path, kmer_size, output_bam,
+                                       threads=4):
+    """Child records carrying a proband-unique k-mer -> sorted, indexed BAM with
+    ``dk:i:1`` on every record (reference :1979-2079).  Same selection: secondary
+    and duplicate records skipped, unmapped and low-MAPQ ones kept, first record
+    per (query name, is_supplementary).  The probe is the engine's scan kernel
+    (the reference dispatches to ``jellyfish query`` or an Aho-Corasick automaton
+    on the same three input kinds); the copy, sort and index are
+    ``kdf_bam_write_subset`` instead of pysam / ``samtools sort`` / ``samtools index``.
+    Returns the number of records written."""
+    from ..core import bam_scanner
+    from ..reads import bam_reader, write_bam_subset
+    bam_scanner._init_scan_worker(proband_unique_kmers_or_path or set(), kmer_size)
+    eng = bam_scanner._worker_engine
+    ordinals, written = [], set()
+    try:
+        with bam_reader(child_bam, flag_off=bam_scanner.FLAG_OFF_MODULE3, collapse=False,
+                        max_bases=bam_scanner.SCAN_BATCH_BASES, max_reads=1 << 20, threads=threads,
+                        want_meta=True) as rd:
+            for batch in rd:
+                _hits, distinct = eng.scan(batch)
+                for r in np.flatnonzero(distinct >= 1).tolist():
+                    key = (batch.name(r), bool(int(batch.flags[r]) & 0x800))
+                    if key not in written:
+                        written.add(key)
+                        ordinals.append(int(batch.ordinals[r]))
+        n = write_bam_subset(child_bam, output_bam, ordinals, [b"dkC\x01"] * len(ordinals), sort_and_index=True,
+                             threads=threads)
+    except KdfError as e:
+        raise RuntimeError(f"informative reads BAM failed: {e}") from e
+    logger.info("Informative reads BAM written: %s (%d reads)", output_bam, n)
+    return n

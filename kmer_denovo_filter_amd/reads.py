@@ -45,6 +45,7 @@ class ReadStream:
     positions: Optional[np.ndarray] = None
     name_buf: Optional[bytes] = None          # NUL-terminated names, back to back
     name_offsets: Optional[np.ndarray] = None
+    ordinals: Optional[np.ndarray] = None     # uint64[n_reads]: record number in the BAM file (write_bam_subset)
     # alignment details (bam_reader(..., want_aux=True))
     cigar: Optional[np.ndarray] = None        # uint32, BAM encoding (len << 4 | op), all records back to back
     cigar_offsets: Optional[np.ndarray] = None  # int64[n_reads + 1]
@@ -126,12 +127,14 @@ class ReadStream:
 class _Reader:
     """Iterator over ReadStream batches from a native kdf_reader."""
 
-    def __init__(self, handle, max_bases: int, max_reads: int, want_meta: bool, want_aux: bool = False):
+    def __init__(self, handle, max_bases: int, max_reads: int, want_meta: bool, want_aux: bool = False,
+                 is_bam: bool = False):
         self._h = handle
         self.max_bases = int(max_bases)
         self.max_reads = int(max_reads)
         self.want_meta = want_meta or want_aux
         self.want_aux = want_aux
+        self.is_bam = is_bam
         self._lib = _native.load()
         if want_aux:
             _native.check_reader(self._lib.kdf_reader_want_aux(self._h, 1), self._h)
@@ -183,6 +186,10 @@ class _Reader:
                 end = last + len(ctypes.string_at(base + last)) + 1
                 st.name_buf = ctypes.string_at(base, end)
                 st.name_offsets = offs
+                if self.is_bam:
+                    od = POINTER(c_uint64)()
+                    _native.check_reader(lib.kdf_reader_last_ordinals(self._h, byref(od)), self._h)
+                    st.ordinals = np.ctypeslib.as_array(od, (n,)).copy()
             if self.want_aux:
                 from ctypes import c_uint32
                 cg, cgo = POINTER(c_uint32)(), POINTER(c_int64)()
@@ -218,7 +225,29 @@ def bam_reader(path: str, flag_off: int = FLAG_OFF_SAMTOOLS_FASTA, collapse: boo
     h = c_void_p()
     rc = _native.load().kdf_bam_open(path.encode(), flag_off, 1 if collapse else 0, threads, byref(h))
     _native.check_reader(rc, None)
-    return _Reader(h, max_bases, max_reads, want_meta, want_aux)
+    return _Reader(h, max_bases, max_reads, want_meta, want_aux, is_bam=True)
+
+
+def write_bam_subset(src_bam: str, dst_bam: str, ordinals, aux_fields=None, sort_and_index: bool = True,
+                     threads: int = 1) -> int:
+    """Copy the records ``ordinals`` (ReadStream.ordinals values) of ``src_bam`` into
+    ``dst_bam``; ``aux_fields[i]`` (bytes, BAM-encoded optional fields) is appended to
+    record i.  With ``sort_and_index``: coordinate sorted + ``.bai`` (the reference's
+    ``pysam.sort`` + ``pysam.index``).  Returns the number of records written."""
+    order = np.argsort(np.asarray(ordinals, dtype=np.uint64), kind="stable")
+    od = np.ascontiguousarray(np.asarray(ordinals, dtype=np.uint64)[order])
+    aux = offs = None
+    if aux_fields is not None:
+        parts = [bytes(aux_fields[i]) for i in order.tolist()]
+        offs = np.zeros(len(parts) + 1, np.uint64)
+        if parts:
+            offs[1:] = np.cumsum([len(x) for x in parts])
+        aux = np.frombuffer(b"".join(parts), np.uint8) if int(offs[-1]) else np.zeros(1, np.uint8)
+    nw = c_uint64(0)
+    rc = _native.load().kdf_bam_write_subset(src_bam.encode(), dst_bam.encode(), _vp(od), len(od), _vp(aux), _vp(offs),
+                                             1 if sort_and_index else 0, threads, byref(nw))
+    _native.check_reader(rc, None)
+    return nw.value
 
 
 def fasta_reader(path: str, k: int, max_bases: int = 1 << 26, max_reads: int = 1 << 16,

@@ -165,3 +165,63 @@ def annotate_variants(variants, variant_read_kmers, parent_found_kmers):
                     "max_pkc": mx, "avg_pkc": av, "min_pkc": mn,
                     "max_pkc_alt": mxa, "avg_pkc_alt": ava, "min_pkc_alt": mna}
     return out
+
+
+def informative_reads_by_variant(variants, variant_read_kmers, parent_found_kmers):
+    """{variant key: names of reads with a variant-spanning k-mer absent from both
+    parents} (reference :1680-1690, the input of ``_write_informative_reads``)."""
+    parent_set = set(parent_found_kmers)
+    out = {}
+    for var in variants:
+        key = _variant_key(var)
+        names = {name for name, kmers, _s in variant_read_kmers.get(key, []) if not kmers.issubset(parent_set)}
+        if names:
+            out[key] = names
+    return out
+
+
+def _write_informative_reads(child_bam, ref_fasta, informative_reads_by_variant, output_bam, threads=4):
+    """Child reads carrying informative k-mers -> sorted, indexed BAM, each tagged
+    ``DV:Z:<comma-joined sorted variant keys>`` (reference :1307-1357).  The reference
+    fetches each variant position in sorted (chrom, pos) order and writes the first
+    record it meets per read name; the same record is picked here from one pass
+    over the file: smallest (region rank, file order) among the records of that
+    name overlapping a variant position."""
+    import bisect
+    from ..core.bam_scanner import reference_end
+    from ..reads import write_bam_subset
+    read_to_variants = {}
+    for var_key, names in informative_reads_by_variant.items():
+        for name in names:
+            read_to_variants.setdefault(name, set()).add(var_key)
+    regions = sorted({(k.split(":")[0], int(k.split(":")[1])) for k in informative_reads_by_variant})
+    rank = {r: i for i, r in enumerate(regions)}
+    by_chrom = collections.defaultdict(list)
+    for c, p in regions:
+        by_chrom[c].append(p)
+    best = {}                                            # name -> (region rank, ordinal)
+    rd = bam_reader(child_bam, flag_off=0, collapse=False, max_bases=1 << 24, threads=threads, want_aux=True)
+    refs = rd.references()
+    with rd:
+        for batch in rd:
+            for i in range(batch.n_reads):
+                rid = int(batch.ref_ids[i])
+                if rid < 0 or refs[rid] not in by_chrom:
+                    continue
+                name = batch.name(i)
+                if name not in read_to_variants:
+                    continue
+                start = int(batch.positions[i])
+                end = reference_end(start, batch.cigartuples(i))
+                if end <= start:
+                    end = start + 1
+                plist = by_chrom[refs[rid]]
+                j = bisect.bisect_left(plist, start)
+                if j < len(plist) and plist[j] < end:
+                    cand = (rank[(refs[rid], plist[j])], int(batch.ordinals[i]))
+                    if name not in best or cand < best[name]:
+                        best[name] = cand
+    names = sorted(best, key=lambda n: best[n][1])
+    aux = [b"DVZ" + ",".join(sorted(read_to_variants[n])).encode() + b"\0" for n in names]
+    return write_bam_subset(child_bam, output_bam, [best[n][1] for n in names], aux, sort_and_index=True,
+                            threads=threads)

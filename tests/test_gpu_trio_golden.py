@@ -208,3 +208,58 @@ def test_vcf_mode_goldens(tmp_path):
                int(g[8]), float(g[9]), int(g[10])]
         assert got == exp, (key, got, exp)
     assert ann["chr19:15018719:G:A"]["max_pkc"] == 2177 and ann["chr18:62805215:A:ATAATATACACTGCATAGGTTATACATATACAGTG"]["avg_pkc"] == 683.58
+
+
+def test_informative_reads_bam_discovery(oracle, discovery, tmp_path):
+    """N4, discovery mode (reference tests/test_example_output_discovery.py:112-121 only
+    ask for a non-empty BAM; here the selection is pinned against the oracle: every
+    primary/supplementary, non-duplicate record with >= 1 proband-unique k-mer, first
+    per (name, is_supplementary), each tagged dk, coordinate sorted, indexed)."""
+    from kmer_denovo_filter_amd.discovery.pipeline import _write_informative_reads_discovery
+    child = os.path.join(GIAB, "HG002_child.bam")
+    out = str(tmp_path / "giab_discovery.informative.bam")
+    n = _write_informative_reads_discovery(child, None, discovery["proband_fa"], 31, out)
+    lo, hi = discovery["proband_unique"][1]
+    kmers = [oracle.int_to_kmer((int(h) << 64) | int(l), 31) for l, h in zip(lo, hi)]
+    table = oracle.OracleTable(31, 4096).count_reads(kmers)
+    _refs, recs = oracle.read_bam(child)
+    recs = [r for r in recs if not (r.is_secondary or r.is_duplicate)]
+    _hit, distinct = table.scan_reads(oracle.concat_reads([r.seq for r in recs]))
+    exp, seen = [], set()
+    for r, d in zip(recs, distinct):
+        key = (r.qname, r.is_supplementary)
+        if d >= 1 and key not in seen:
+            seen.add(key); exp.append((r.qname, r.flag, r.ref_id, r.pos))
+    assert n == len(exp) > 195                       # min_distinct 1 here, 7 in Module 3's metric
+    _refs2, got = oracle.read_bam(out)
+    got = list(got)
+    assert sorted((r.qname, r.flag, r.ref_id, r.pos) for r in got) == sorted(exp)
+    keys = [((r.ref_id & 0xFFFFFFFF), r.pos) for r in got]
+    assert keys == sorted(keys) and os.path.getsize(out + ".bai") > 8 and not os.path.exists(out + ".unsorted.bam")
+    import gzip
+    raw = gzip.open(out).read()
+    assert raw.count(b"dkC\x01") >= n
+
+
+def test_informative_reads_bam_vcf_mode(tmp_path):
+    """N4, VCF mode: reads named in informative_reads_by_variant, one record per name
+    (first met walking the variant positions in sorted order), DV:Z tag."""
+    import gzip
+    from kmer_denovo_filter_amd.vcf.pipeline import (_collect_child_kmers, _parse_vcf_variants, _write_informative_reads,
+                                                     informative_reads_by_variant, scan_parents)
+    child = os.path.join(GIAB, "HG002_child.bam")
+    variants = _parse_vcf_variants(os.path.join(GIAB, "candidates.vcf.gz"), proband_id="HG002")
+    fa = str(tmp_path / "child_kmers.fa")
+    total, per_variant = _collect_child_kmers(child, None, variants, 31, 20, 20, False, fa)
+    found = scan_parents(os.path.join(GIAB, "HG004_mother.bam"), os.path.join(GIAB, "HG003_father.bam"), None, fa,
+                         31, str(tmp_path), 4, total)
+    by_var = informative_reads_by_variant(variants, per_variant, found)
+    assert len(by_var) == 12                                        # metrics.json variants_with_unique_reads
+    out = str(tmp_path / "informative.bam")
+    n = _write_informative_reads(child, None, by_var, out)
+    names = set().union(*by_var.values())
+    assert n == len(names)
+    raw = gzip.open(out).read()
+    for key, rn in by_var.items():
+        assert raw.count(key.encode()) >= len(rn)
+    assert os.path.exists(out + ".bai")
