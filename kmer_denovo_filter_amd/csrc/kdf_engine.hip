@@ -227,6 +227,7 @@ struct kdf_engine {
     int device = 0;
     int k = 0;
     int kw = 1;
+    int n_cu = 256;               // compute units of the device (persistent-kernel grids)
     KdfTable t{};                 // live table
     uint64_t cap = 0;
     KdfCtl *ctl = nullptr;        // device
@@ -466,9 +467,14 @@ template <int KW>
 static int kb_set_lds_attrs(kdf_engine *h, size_t a1, size_t b, size_t c) {
     HIPCHK(h, hipFuncSetAttribute((const void *)kb_scatter1_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a1));
     HIPCHK(h, hipFuncSetAttribute((const void *)kb_finesort_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b));
-    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_INSERT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c));
-    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_FILTERED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c));
-    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_REPLAY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c));
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_INSERT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c));
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_FILTERED, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c));
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_REPLAY, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c));
+#define KB_SETV(V) \
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_INSERT, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(c + KB_C_QEXTRA(V)))); \
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_FILTERED, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(c + KB_C_QEXTRA(V))));
+    if constexpr (KW == 1) { KB_SETV(1) }
+#undef KB_SETV
     return KDF_OK;
 }
 
@@ -537,11 +543,17 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     hipLaunchKernelGGL(kb_finesort_kernel<KW>, dim3((unsigned)n_chunks), dim3(KB_THREADS), lds_b, h->stream, plan, s);
     stamp();                                                   // end of B
     if (filtered && (rc = materialize(h))) return rc;
+    // narrow keys: lookahead + wave-queue variant of kernel C (debug flag 8 selects the plain loop, for A/B runs)
+    const bool var1 = KW == 1 && !(h->opt_debug_flags & 8);
     const int nonempty = h->lazy_empty ? 0 : 1;   // 0: kernel C rewrites every bucket (this IS the clear)
     if (filtered)
-        hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_FILTERED>), dim3((unsigned)nb_table), dim3(KB_C_THREADS), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty);
+#define KB_LV(M, V) hipLaunchKernelGGL((kb_bucket_kernel<KW, M, V>), dim3((unsigned)nb_table), dim3(KB_C_THREADS), lds_c + KB_C_QEXTRA(V), h->stream, plan, s, h->t, h->ctl, nonempty)
+#define KB_LVS(M) do { if constexpr (KW == 1) KB_LV(M, 1); } while (0)
+        if (var1) KB_LVS(KB_MODE_FILTERED);
+        else hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_FILTERED, 0>), dim3((unsigned)nb_table), dim3(KB_C_THREADS), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty);
     else
-        hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_INSERT>), dim3((unsigned)nb_table), dim3(KB_C_THREADS), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty);
+        if (var1) KB_LVS(KB_MODE_INSERT);
+        else hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_INSERT, 0>), dim3((unsigned)nb_table), dim3(KB_C_THREADS), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty);
     HIPCHK(h, hipGetLastError());
     if (h->prof) {
         stamp();                                               // end of C
@@ -569,7 +581,7 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     const uint64_t worst = h->distinct + std::min<uint64_t>(n_entries, n_failed * ((n_entries / std::max<uint64_t>(nb_table, 1)) * 4 + 4096));
     uint32_t want = std::max<uint32_t>(h->t.log2cap + 1, cap_log2_for(worst));
     if ((rc = table_rehash(h, want))) return rc;
-    hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_REPLAY>), dim3((unsigned)nb_table), dim3(KB_C_THREADS), lds_c, h->stream, plan, s, h->t, h->ctl, 1);
+    hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_REPLAY, 0>), dim3((unsigned)nb_table), dim3(KB_C_THREADS), lds_c, h->stream, plan, s, h->t, h->ctl, 1);
     HIPCHK(h, hipGetLastError());
     if ((rc = ctl_sync(h, &full))) return rc;
     if (full) return fail(h, KDF_ERR_TABLE_FULL, "binned count: bucket overflow during replay (capacity 2^%u)", h->t.log2cap);
@@ -682,6 +694,7 @@ int kdf_create(int device, int k, uint64_t capacity_hint, kdf_engine **out) {
     h->device = device; h->k = k; h->kw = k <= 32 ? 1 : 2;
     auto bail = [&](int rc) { g_err = h->err; kdf_destroy(h); return rc; };
     if ((e = hipSetDevice(device)) != hipSuccess) { h->err = hipGetErrorString(e); return bail(KDF_ERR_HIP); }
+    { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) h->n_cu = ncu; }
     if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) { h->err = hipGetErrorString(e); return bail(KDF_ERR_HIP); }
     h->stream = h->own_stream;
     if ((e = hipMalloc((void **)&h->ctl, sizeof(KdfCtl))) != hipSuccess) { h->err = hipGetErrorString(e); return bail(KDF_ERR_NOMEM); }
