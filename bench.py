@@ -88,26 +88,48 @@ def main():
         merger = OwnerPartitionedCount(EngineOps(eng, dev), dist.group.WORLD, dev,
                                        owner_ops=EngineOps(owner_eng, dev))
 
+    # N = 1: a step is clear -> count the batch -> `dump -L 3` threshold (BASELINE config 2).
+    # N > 1: the streamed-sample job of SURVEY.md section 8d item 4 / 8e: every rank counts
+    # K batches of ITS read shard into its local table (one step each, no communication), then
+    # ONE owner-partitioned exchange + owner-side sum + global threshold closes the job --
+    # all inside the timed region; its share of the time is reported as config.merge_ms.
     def step():
-        eng.clear()
         if merger is None:
+            eng.clear()
             eng.count_dev(ds.packed.data_ptr(), ds.invalid.data_ptr(), ds.n_bases)
             return eng.count_ge(3)
-        return merger.count_and_merge(ds.packed, ds.invalid, ds.n_bases, min_count=3)
+        merger.count_local(ds.packed, ds.invalid, ds.n_bases)
+        return 0
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    _, distinct, windows = eng.stats() if merger is None else merger.local_stats()
+    merge_ms = 0.0
+    if merger is None:
+        for _ in range(args.warmup):
+            step()
+        _, distinct, windows = eng.stats()
+    else:
+        merger.clear()
+        for _ in range(max(args.warmup, 1)):       # one full mini-job: warms RCCL too
+            step()
+        merger.merge(3)
+        _, distinct, windows = merger.local_stats()
+        windows //= max(args.warmup, 1)
+        merger.clear()
     barrier()
     eng.profile(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         n_ge3 = step()
+    if merger is not None:
+        torch.cuda.synchronize()
+        tm = time.perf_counter()
+        n_ge3 = merger.merge(3)
+        torch.cuda.synchronize()
+        merge_ms = (time.perf_counter() - tm) * 1e3
     barrier()
     dt = time.perf_counter() - t0
     kernel_ms, launches, positions = eng.profile_read()
@@ -170,6 +192,11 @@ def main():
             "reads_per_gpu": args.reads, "read_len": L, "k": k,
             "windows_per_gpu": windows, "distinct_per_gpu": distinct, "kmers_ge3": int(n_ge3),
             "table_slots": eng.stats()[0],
+            "multi_gpu": None if world == 1 else {
+                "job": f"{args.steps} local count steps per rank (no communication), then ONE owner-partitioned "
+                       "all-to-all of (key,count) pairs + owner-side sum + global dump -L 3, all inside the timed region",
+                "merge_ms": round(merge_ms, 3), "exchanged_pairs_rank0": merger.last_exchange_pairs,
+            },
         },
         "roofline": {
             "bound": "hbm",

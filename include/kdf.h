@@ -165,6 +165,16 @@ int kdf_export_ge(kdf_engine *h, uint32_t min_count, uint64_t *keys_lo_out,
 int kdf_export_ge_dev(kdf_engine *h, uint32_t min_count, void *d_keys_lo_out,
                       void *d_keys_hi_out, void *d_counts_out, uint64_t cap,
                       int sorted, uint64_t *n_out);
+/* The multi-GPU exchange of the full count stage (Jellyfish `merge`,
+ * core/jellyfish_wrappers.py:335-366, done over xGMI): dump every (key, count >= min_count)
+ * pair to DEVICE arrays grouped by owner rank, owner(key) = ((hash(key) >> 48) * parts) >> 16
+ * with the table's own hash -- so the owners are contiguous slot ranges and no sort or
+ * partition pass is needed.  part_counts_out[parts] (host) receives the pairs per owner;
+ * part p occupies [sum(counts[0..p)), +counts[p]) of the outputs, unordered inside.
+ * parts <= 64; KDF_ERR_STATE when the table is smaller than 2^28 (2^27 wide) slots. */
+int kdf_export_parts_dev(kdf_engine *h, uint32_t min_count, uint32_t parts, void *d_keys_lo_out,
+                         void *d_keys_hi_out, void *d_counts_out, uint64_t cap,
+                         uint64_t *part_counts_out, uint64_t *n_out);
 
 /* ------------------------------------------------------ Module-3 scan ---- */
 

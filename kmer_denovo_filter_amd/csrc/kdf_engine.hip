@@ -148,13 +148,17 @@ __global__ __launch_bounds__(256) void kdf_query_kernel(
 template <int KW, bool WRITE>
 __global__ __launch_bounds__(256) void kdf_export_kernel(
     KdfTable t, uint32_t min_count, KdfCtl *ctl, uint64_t *__restrict__ olo,
-    uint64_t *__restrict__ ohi, uint32_t *__restrict__ ocnt, uint64_t out_cap)
+    uint64_t *__restrict__ ohi, uint32_t *__restrict__ ocnt, uint64_t out_cap, uint32_t parts)
 {
     const uint64_t cap = 1ull << t.log2cap;
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint64_t first = wave * (KDF_EXPORT_ROWS * 64);
     if (first >= cap) return;
+    // parts > 0: output grouped by owner rank, owner(key) = ((hash >> 48) * parts) >> 16.  The
+    // top 16 hash bits are the top 16 bits of the home slot and a key never leaves its bucket,
+    // so (host-checked: log2cap - 16 >= max(11, bucket_bits)) all slots of this wave have one owner.
+    const uint32_t part = parts ? (uint32_t)((((first >> (t.log2cap - 16)) & 0xFFFFu) * parts) >> 16) : 0u;
     uint32_t mine = 0;
     if (!WRITE && min_count >= 1 && first + KDF_EXPORT_ROWS * 64 <= cap) {
         // count > 0 implies the slot is occupied: stream the counts array only, 16 B per lane
@@ -182,11 +186,12 @@ __global__ __launch_bounds__(256) void kdf_export_kernel(
     for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
     if (tot == 0) return;
     if (!WRITE) {      // counting pass: no positions needed, spread the adds over 64 lines
-        if (lane == 0) atomicAdd(&ctl->tally[(wave % KDF_SHARDS) * 16], (unsigned long long)tot);
+        if (lane == 0) atomicAdd(&ctl->tally[(parts ? part : (uint32_t)(wave % KDF_SHARDS)) * 16], (unsigned long long)tot);
         return;
     }
     unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(&ctl->cursor, (unsigned long long)tot);
+    // parts: tally[part] was preloaded with the part's offset and serves as its cursor
+    if (lane == 0) base = parts ? atomicAdd(&ctl->tally[part * 16], (unsigned long long)tot) : atomicAdd(&ctl->cursor, (unsigned long long)tot);
     base = __shfl(base, 0);
     for (int r = 0; r < KDF_EXPORT_ROWS; ++r) {
         const uint64_t i = first + (uint64_t)r * 64 + lane;
@@ -936,23 +941,66 @@ int kdf_query(kdf_engine *h, const uint64_t *keys_lo, const uint64_t *keys_hi, u
 }
 
 static int export_pass(kdf_engine *h, uint32_t min_count, bool write, uint64_t *olo, uint64_t *ohi,
-                       uint32_t *ocnt, uint64_t out_cap, uint64_t *n_out) {
+                       uint32_t *ocnt, uint64_t out_cap, uint64_t *n_out, uint32_t parts = 0, uint64_t *part_vals = nullptr) {
     { int rc0 = materialize(h); if (rc0) return rc0; }
     HIPCHK(h, hipMemsetAsync(h->ctl->tally, 0, sizeof(h->ctl->tally) + 8, h->stream));   // tally[] + cursor
+    std::vector<unsigned long long> stage;
+    if (parts && write) {                                   // preload the per-part cursors with the part offsets
+        stage.assign(KDF_SHARDS * 16, 0ull);
+        for (uint32_t p = 0; p < parts; ++p) stage[p * 16] = part_vals[p];
+        HIPCHK(h, hipMemcpyAsync(h->ctl->tally, stage.data(), sizeof(h->ctl->tally), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));         // `stage` is pageable
+    }
     const uint64_t waves = (h->cap + KDF_EXPORT_ROWS * 64 - 1) / (KDF_EXPORT_ROWS * 64);
     const unsigned blocks = (unsigned)((waves + 3) / 4);
     if (h->kw == 1) {
-        if (write) hipLaunchKernelGGL((kdf_export_kernel<1, true>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap);
-        else hipLaunchKernelGGL((kdf_export_kernel<1, false>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap);
+        if (write) hipLaunchKernelGGL((kdf_export_kernel<1, true>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap, parts);
+        else hipLaunchKernelGGL((kdf_export_kernel<1, false>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap, parts);
     } else {
-        if (write) hipLaunchKernelGGL((kdf_export_kernel<2, true>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap);
-        else hipLaunchKernelGGL((kdf_export_kernel<2, false>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap);
+        if (write) hipLaunchKernelGGL((kdf_export_kernel<2, true>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap, parts);
+        else hipLaunchKernelGGL((kdf_export_kernel<2, false>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap, parts);
     }
     HIPCHK(h, hipGetLastError());
+    if (parts) {                                            // per-part tallies (count pass) / end cursors (write pass)
+        stage.assign(KDF_SHARDS * 16, 0ull);
+        HIPCHK(h, hipMemcpyAsync(stage.data(), h->ctl->tally, sizeof(h->ctl->tally), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        uint64_t tot = 0;
+        for (uint32_t p = 0; p < parts; ++p) { if (!write) { part_vals[p] = stage[p * 16]; tot += stage[p * 16]; } else tot = stage[p * 16]; }
+        *n_out = tot;                                       // write pass: end of the last part = total
+        return KDF_OK;
+    }
     uint64_t cursor = 0;
     int rc = ctl_sync(h, nullptr, &cursor);
     if (rc) return rc;
     *n_out = cursor;
+    return KDF_OK;
+}
+
+int kdf_export_parts_dev(kdf_engine *h, uint32_t min_count, uint32_t parts, void *d_keys_lo_out, void *d_keys_hi_out,
+                         void *d_counts_out, uint64_t cap, uint64_t *part_counts_out, uint64_t *n_out) {
+    if (!h || !n_out || !part_counts_out) return fail(h, KDF_ERR_INVALID, "kdf_export_parts_dev: NULL pointer");
+    if (parts < 1 || parts > KDF_SHARDS) return fail(h, KDF_ERR_INVALID, "kdf_export_parts_dev: parts must be 1..%d", KDF_SHARDS);
+    HIPCHK(h, hipSetDevice(h->device));
+    { int rc0 = materialize(h); if (rc0) return rc0; }
+    if (h->t.log2cap < 16 + std::max<uint32_t>(11, h->t.bucket_bits))
+        return fail(h, KDF_ERR_STATE, "kdf_export_parts_dev: table of 2^%u slots is too small for an owner-ordered dump (needs 2^%u)",
+                    h->t.log2cap, 16 + std::max<uint32_t>(11, h->t.bucket_bits));
+    uint64_t n = 0;
+    int rc = export_pass(h, min_count, false, nullptr, nullptr, nullptr, 0, &n, parts, part_counts_out);
+    if (rc) return rc;
+    *n_out = n;
+    if (n == 0) return KDF_OK;
+    if (n > cap) return fail(h, KDF_ERR_INVALID, "kdf_export_parts_dev: %llu entries, room for %llu", (unsigned long long)n, (unsigned long long)cap);
+    if (!d_keys_lo_out || (h->kw == 2 && !d_keys_hi_out)) return fail(h, KDF_ERR_INVALID, "kdf_export_parts_dev: NULL key output");
+    std::vector<uint64_t> offs(parts);
+    uint64_t acc = 0;
+    for (uint32_t p = 0; p < parts; ++p) { offs[p] = acc; acc += part_counts_out[p]; }
+    uint64_t n2 = 0;
+    rc = export_pass(h, min_count, true, (uint64_t *)d_keys_lo_out, h->kw == 2 ? (uint64_t *)d_keys_hi_out : nullptr,
+                     (uint32_t *)d_counts_out, n, &n2, parts, offs.data());
+    if (rc) return rc;
+    if (n2 != n) return fail(h, KDF_ERR_STATE, "kdf_export_parts_dev: table changed between passes");
     return KDF_OK;
 }
 

@@ -37,14 +37,23 @@ import torch.distributed as dist
 _U32_MAX = 0xFFFFFFFF
 
 
+def _lsr(x: torch.Tensor, n: int) -> torch.Tensor:
+    """Logical right shift of int64 bit patterns."""
+    return (x >> n) & ((1 << (64 - n)) - 1)
+
+
 def owner_of(lo: torch.Tensor, hi: Optional[torch.Tensor], world: int) -> torch.Tensor:
-    """Owner rank of each key: a fixed mix of the key bits, independent of any
-    table's hash/layout (int64 arithmetic wraps like uint64)."""
-    x = lo ^ (lo >> 31)
+    """Owner rank of each key: ``((hash >> 48) * world) >> 16`` with the TABLE's hash
+    (csrc/kdf_device.h ``kdf_hash``; int64 arithmetic wraps like uint64).  The top
+    hash bits are the top bits of a key's home slot, so on every rank the keys of
+    one owner sit in one contiguous slot range and the engine can dump them grouped
+    by owner without a sort (``kdf_export_parts_dev``).  It depends on the key only
+    -- not on any table's size."""
+    x = lo
     if hi is not None:
-        x = x ^ (hi * 0x2545F4914F6CDD1D)
-    x = (x * 0x9E3779B97F4A7C15 - 0) >> 40           # arithmetic shift; sign handled by the mask
-    return (x & 0x7FFFFF) % world
+        x = lo ^ ((hi << 37) | _lsr(hi, 27))
+    h = (x ^ _lsr(x, 32)) * -0x61C8864680B583EB           # 0x9E3779B97F4A7C15 as int64
+    return (_lsr(h, 48) * world) >> 16
 
 
 class TableOps:
@@ -96,6 +105,21 @@ class EngineOps(TableOps):
                                        cnt.data_ptr(), n)
             assert got == n
         return lo, hi, cnt
+
+    def export_pairs_by_owner(self, world: int):
+        """(lo, hi, cnt, per-owner counts) already grouped by owner rank, or None when
+        the table is too small for the engine's owner-ordered dump."""
+        if self.e.get_stat("log2cap") < 16 + max(11, self.e.get_stat("bucket_bits")) or world > 64:
+            return None
+        _, distinct, _ = self.e.stats()
+        lo = torch.empty(distinct, dtype=torch.int64, device=self.device)
+        hi = torch.empty(distinct, dtype=torch.int64, device=self.device) if self.wide else None
+        cnt = torch.empty(distinct, dtype=torch.int32, device=self.device)
+        self._sync()
+        n, counts = self.e.export_parts_dev(0, world, lo.data_ptr(), hi.data_ptr() if hi is not None else None,
+                                            cnt.data_ptr(), distinct)
+        self.e.synchronize()
+        return lo[:n], (hi[:n] if hi is not None else None), cnt[:n], counts
 
     def add_pairs(self, lo, hi, cnt):
         if lo.numel() == 0:
@@ -170,12 +194,17 @@ class OwnerPartitionedCount:
         """Move every locally counted (key, count) pair to its owner rank."""
         if self.world == 1:
             return
-        lo, hi, cnt = self.local.export_pairs(0)
-        own = owner_of(lo, hi, self.world)
-        order = torch.argsort(own, stable=True)
-        lo, cnt = lo[order], cnt[order]
-        hi = hi[order] if hi is not None else None
-        send_counts = torch.bincount(own, minlength=self.world).to(torch.int64)
+        grouped = self.local.export_pairs_by_owner(self.world) if hasattr(self.local, "export_pairs_by_owner") else None
+        if grouped is not None:                      # the engine dumps owner by owner: nothing to sort
+            lo, hi, cnt, counts = grouped
+            send_counts = torch.tensor(counts, dtype=torch.int64, device=self.device)
+        else:
+            lo, hi, cnt = self.local.export_pairs(0)
+            own = owner_of(lo, hi, self.world)
+            order = torch.argsort(own, stable=True)
+            lo, cnt = lo[order], cnt[order]
+            hi = hi[order] if hi is not None else None
+            send_counts = torch.bincount(own, minlength=self.world).to(torch.int64)
         recv_counts = torch.empty_like(send_counts)
         dist.all_to_all_single(recv_counts, send_counts, group=self.group)
         s_list: List[int] = send_counts.tolist()
@@ -194,18 +223,31 @@ class OwnerPartitionedCount:
         rcnt = a2a(cnt)
         self.owner.add_pairs(rlo, rhi, rcnt)
 
-    def count_and_merge(self, packed, invalid, n_bases: int, min_count: int = 1) -> int:
-        """clear -> count the local shard -> exchange -> global number of keys
-        with count >= min_count (``dump -L``)."""
-        if isinstance(packed, int):
-            raise TypeError("pass the stream tensors, not raw pointers")
+    def clear(self):
         self.local.clear()
         if self.owner is not self.local:
             self.owner.clear()
+
+    def count_local(self, packed, invalid, n_bases: int):
+        """Count one more batch of this rank's read shard into its LOCAL table (no
+        communication: a streamed sample is many such batches, then one merge)."""
+        if isinstance(packed, int):
+            raise TypeError("pass the stream tensors, not raw pointers")
         self.local.count_stream(packed, invalid, n_bases)
         self._local_stats = self.local.stats()
+
+    def merge(self, min_count: int = 1) -> int:
+        """Exchange the local (key, count) pairs to their owners; returns the global
+        number of keys with count >= min_count (``dump -L``)."""
         self.exchange()
         n = torch.tensor([self.owner.count_ge(min_count)], dtype=torch.int64, device=self.device)
         if self.world > 1:
             dist.all_reduce(n, op=dist.ReduceOp.SUM, group=self.group)
         return int(n.item())
+
+    def count_and_merge(self, packed, invalid, n_bases: int, min_count: int = 1) -> int:
+        """clear -> count the local shard -> exchange -> global number of keys
+        with count >= min_count."""
+        self.clear()
+        self.count_local(packed, invalid, n_bases)
+        return self.merge(min_count)

@@ -197,6 +197,17 @@ class KmerEngine:
                                              1 if sorted_ else 0, byref(n)))
         return n.value
 
+    def export_parts_dev(self, min_count: int, parts: int, d_lo: int, d_hi: Optional[int], d_cnt: Optional[int],
+                         cap: int):
+        """Dump grouped by owner rank (distributed.owner_of) into caller-owned device
+        buffers; returns (entries, per-owner counts)."""
+        n = c_uint64(0)
+        counts = (c_uint64 * int(parts))()
+        self._ck(self._lib.kdf_export_parts_dev(self._h, int(min_count), int(parts), c_void_p(d_lo),
+                                                c_void_p(d_hi) if d_hi else None,
+                                                c_void_p(d_cnt) if d_cnt else None, int(cap), counts, byref(n)))
+        return n.value, [int(x) for x in counts]
+
     # -- Module-3 scan -----------------------------------------------------
     def scan(self, stream: ReadStream, want_distinct: bool = True):
         """-> (hit_bits uint64[mask words], distinct uint32[n_reads] or None)."""

@@ -5,7 +5,7 @@ from kmer_denovo_filter_amd.synth import synth_stream
 flags_list = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 8, 0, 8]
 ds = synth_stream(10_000_000, 150, 100_000_000, seed=20260417, device="cuda:0"); torch.cuda.synchronize()
 for flags in flags_list:
-    with KmerEngine(31, capacity_hint=1 << 28) as e:
+    with KmerEngine(int(sys.argv[2]) if len(sys.argv) > 2 else 31, capacity_hint=1 << 28) as e:
         e.set_option("debug_flags", flags)
         best = 1e9
         for it in range(4):

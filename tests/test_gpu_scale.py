@@ -135,3 +135,42 @@ def test_owner_exchange_gpu_pieces_two_virtual_ranks(oracle):
         np.testing.assert_array_equal(merged, exp_local.astype(np.int64))
         for o in local + owner:
             o.e.close()
+
+
+def test_owner_ordered_dump_matches_owner_of():
+    """kdf_export_parts_dev (the exchange's send side): every pair appears once, in the
+    segment of the rank owner_of names, for power-of-two and odd world sizes, narrow and
+    wide keys; a table too small for contiguous owner ranges is refused, not mis-grouped."""
+    import torch
+    from kmer_denovo_filter_amd import KmerEngine
+    from kmer_denovo_filter_amd._native import KdfError
+    from kmer_denovo_filter_amd.distributed import EngineOps, owner_of
+    from kmer_denovo_filter_amd.synth import synth_stream
+    dev = torch.device("cuda:0")
+    ds = synth_stream(300_000, 150, 3_000_000, seed=77, device=dev)
+    torch.cuda.synchronize()
+    for k in (31, 47):
+        with KmerEngine(k, capacity_hint=1 << 27) as e:                 # 2^28 slots
+            ops = EngineOps(e, dev)
+            ops.count_stream(ds.packed, ds.invalid, ds.n_bases)
+            ref_lo, ref_hi, ref_cnt = ops.export_pairs(0)
+            key = lambda lo, hi, c: torch.stack([lo, hi if hi is not None else torch.zeros_like(lo), c.to(torch.int64)], 1)
+            ref = key(ref_lo, ref_hi, ref_cnt)
+            ref = ref[torch.argsort(ref[:, 0] * 31 + ref[:, 1])].cpu().numpy()
+            ref = ref[np.lexsort((ref[:, 2], ref[:, 1], ref[:, 0]))]
+            for world in (2, 3, 8):
+                lo, hi, cnt, counts = ops.export_pairs_by_owner(world)
+                assert sum(counts) == lo.numel() == ref_lo.numel() and len(counts) == world
+                own = owner_of(lo, hi, world).cpu().numpy()
+                exp = np.repeat(np.arange(world), counts)
+                np.testing.assert_array_equal(own, exp)
+                got = key(lo, hi, cnt).cpu().numpy()
+                got = got[np.lexsort((got[:, 2], got[:, 1], got[:, 0]))]
+                np.testing.assert_array_equal(got, ref)
+    with KmerEngine(31, capacity_hint=1 << 20) as e:
+        ops = EngineOps(e, dev)
+        ops.count_stream(ds.packed, ds.invalid, 151 * 1000)
+        assert ops.export_pairs_by_owner(2) is None                     # adapter falls back to the sort-based split
+        lo = torch.empty(1 << 20, dtype=torch.int64, device=dev); cnt = torch.empty(1 << 20, dtype=torch.int32, device=dev)
+        with pytest.raises(KdfError):
+            e.export_parts_dev(0, 2, lo.data_ptr(), None, cnt.data_ptr(), 1 << 20)
