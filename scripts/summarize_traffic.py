@@ -38,7 +38,7 @@ write, nw = per_kernel("write", "WRITE_SIZE")
 bench = json.load(open(os.path.join(out, "fetch", "bench.json")))
 cfg = bench["config"]
 n_entries = cfg["windows_per_gpu"]
-names = ["kb_hist1_kernel<1>", "kb_scatter1_kernel<1>", "kb_finesort_kernel<1>", "kb_bucket_kernel<1, 0>"]
+names = ("kb_hist1_kernel<1>", "kb_scatter1_kernel<1>", "kb_finesort_kernel<1>", "kb_bucket_kernel<1, 0")   # prefixes of the pass kernels
 rows, total = [], 0.0
 for k in sorted(set(fetch) | set(write)):
     if not (k.startswith("kb_") or k.startswith("kdf_")):
@@ -46,7 +46,7 @@ for k in sorted(set(fetch) | set(write)):
     rd = fetch.get(k, 0.0) * 1024 * 2          # KiB -> B, gfx950 half-count correction
     wr = write.get(k, 0.0) * 1024
     rows.append({"kernel": k, "dispatches": int(nf.get(k, 0)), "read_bytes": rd, "write_bytes": wr})
-    if k in names:
+    if k.startswith(names):
         total += rd + wr
 summary = {
     "tag": tag, "reads_per_gpu": cfg["reads_per_gpu"], "k": cfg["k"], "read_len": cfg["read_len"],
