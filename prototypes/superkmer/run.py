@@ -72,11 +72,38 @@ def extract(ds, cap, reps=3, coarse_bits=9):
     return rec, bkt, [int(x) for x in tot], [float(x) for x in ms]
 
 
-def stage2(rec, bkt, windows, distinct, ge3, nb_bits=17, versions=(1, 2)):
+def bucket_hash(g):
+    """sk_bucket_hash of sk_proto.hip on int64 tensors."""
+    return ((g * 0x9E3779B1) & 0xFFFFFFFF) ^ (g >> 9)
+
+
+def balanced_assignment(rec, g, nb_bits):
+    """minimizer -> bucket table with (nearly) equal DISTINCT-k-mer weight per bucket: weight of a
+    minimizer = k-mers of its distinct records (an upper bound of its distinct k-mers; a product
+    version would estimate it from a sample of the stream), heaviest first, dealt out in snake order."""
+    key = torch.stack([rec[:, 0], rec[:, 1], g], 1)
+    uniq = torch.unique(key, dim=0)
+    w = torch.zeros(1 << 24, dtype=torch.int64, device=rec.device)
+    w.index_add_(0, uniq[:, 2], (uniq[:, 1] >> 58) & 63)
+    order = torch.argsort(w, descending=True)
+    nb = 1 << nb_bits
+    pos = torch.arange(order.numel(), device=rec.device)
+    rnd, off = pos // nb, pos % nb
+    bucket = torch.where(rnd % 2 == 0, off, nb - 1 - off)
+    table = torch.empty(1 << 24, dtype=torch.int64, device=rec.device)
+    table[order] = bucket
+    return table
+
+
+def stage2(rec, gval, windows, distinct, ge3, nb_bits=17, versions=(1, 2), balanced=False):
     """Group the records by bucket (untimed: torch sort stands in for the A1'/B' partition of 2 GB of
     records) and run the bucket kernel; check distinct / sum / count>=3 against the engine."""
     dev = rec.device
-    b = (bkt.to(torch.int64) & 0xFFFFFFFF) >> (32 - nb_bits)
+    g = gval.to(torch.int64) & 0xFFFFFF
+    if balanced:
+        b = balanced_assignment(rec, g, nb_bits).index_select(0, g)
+    else:
+        b = bucket_hash(g) >> (32 - nb_bits)
     order = torch.argsort(b)
     nk0 = int(((rec[:, 1] >> 58) & 63).sum())
     # (advanced indexing rec[order] returned garbage for the upper half at 1.3e8 rows on this torch build: gather per column)
@@ -86,7 +113,7 @@ def stage2(rec, bkt, windows, distinct, ge3, nb_bits=17, versions=(1, 2)):
     counts = torch.bincount(b, minlength=1 << nb_bits)
     boff = torch.zeros((1 << nb_bits) + 1, dtype=torch.int64, device=dev); boff[1:] = torch.cumsum(counts, 0)
     boff32 = boff.to(torch.int32).contiguous()
-    print(f"records per bucket: mean {counts.float().mean().item():.0f} max {counts.max().item()} p99 {int(torch.quantile(counts.float()[:: max(1, counts.numel() // 65536)], 0.99).item())}", flush=True)
+    print(('balanced ' if balanced else 'hashed ') + f"records per bucket: mean {counts.float().mean().item():.0f} max {counts.max().item()} p99 {int(torch.quantile(counts.float()[:: max(1, counts.numel() // 65536)], 0.99).item())}", flush=True)
     tab_lo = torch.empty((1 << nb_bits) * 4096, dtype=torch.int64, device=dev)
     tab_cnt = torch.empty((1 << nb_bits) * 4096, dtype=torch.int32, device=dev)
     for version in versions:
@@ -138,7 +165,8 @@ def main():
     n = tot[2]
     stage2(rec[:n], bkt[:n], tot[1], distinct, ge3)
     stage2(rec[:n], bkt[:n], tot[1], distinct, ge3, nb_bits=18)
-    stage2(rec[:n], bkt[:n], tot[1], distinct, ge3, nb_bits=19, versions=(1,))
+    stage2(rec[:n], bkt[:n], tot[1], distinct, ge3, nb_bits=17, versions=(1,), balanced=True)
+    stage2(rec[:n], bkt[:n], tot[1], distinct, ge3, nb_bits=18, versions=(1,), balanced=True)
     # distinct records / k-mer inserts after dedupe (what stage 2 would insert)
     r = rec[:n]
     t0 = time.time()

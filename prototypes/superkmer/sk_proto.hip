@@ -209,7 +209,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_emit_kernel(const uint64_t *__r
         if (chi < hi || (chi == hi && clo < lo)) { lo = clo; hi = chi; }
         if (pos < out_cap) {
             out[pos].lo = lo; out[pos].hi = hi | ((uint64_t)nk << 58);
-            out_bucket[pos] = sk_bucket_hash(lds_mv[i * SK_THREADS + threadIdx.x]);
+            out_bucket[pos] = lds_mv[i * SK_THREADS + threadIdx.x];     // the minimizer's order value (24 bits): the host picks the bucket function
         }
         ++pos;
     }
