@@ -253,7 +253,7 @@ struct kdf_engine {
     void *kb_buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ent_lo, ent_hi, chunk_off, failed, hist_wg, wg_base
     size_t kb_bytes[6] = {0, 0, 0, 0, 0, 0};
     uint64_t opt_binned_min_positions = 1ull << 22;  // smaller batches use the direct global-table kernels
-    uint32_t opt_binned_filtered_min_log2cap = 24;   // count --if goes binned from 2^24 slots (measured crossover)
+    uint32_t opt_binned_filtered_min_log2cap = 23;   // count --if goes binned from 2^23 slots (measured crossover)
     int opt_force_path = 0;                          // 0 auto, 1 direct, 2 binned
     uint32_t opt_debug_flags = 0;                    // experiments only (KbPlan::dbg)
     uint64_t stat_binned_passes = 0, stat_replayed_buckets = 0;
