@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--genome", type=int, default=100_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N > 1 ranks on ONE GPU: gloo with host-staged collectives instead of RCCL "
+                         "(checks the multi-GPU job end to end on a 1-GPU box; its timing means nothing)")
     args = ap.parse_args()
 
     import torch
@@ -61,10 +64,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if args.rehearse_one_gpu else dev       # where the scalar collectives live
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
@@ -86,7 +95,7 @@ def main():
         owner_eng = KmerEngine(k, capacity_hint=cap_hint, device=local_rank)     # keys this rank owns
         owner_eng.set_stream(torch.cuda.current_stream().cuda_stream)
         merger = OwnerPartitionedCount(EngineOps(eng, dev), dist.group.WORLD, dev,
-                                       owner_ops=EngineOps(owner_eng, dev))
+                                       owner_ops=EngineOps(owner_eng, dev), stage_through_host=args.rehearse_one_gpu)
 
     # N = 1: a step is clear -> count the batch -> `dump -L 3` threshold (BASELINE config 2).
     # N > 1: the streamed-sample job of SURVEY.md section 8d item 4 / 8e: every rank counts
@@ -138,10 +147,10 @@ def main():
     eng.profile(False)
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        w = torch.tensor([windows], dtype=torch.int64, device=dev)
+        w = torch.tensor([windows], dtype=torch.int64, device=cdev)
         dist.all_reduce(w, op=dist.ReduceOp.SUM)
         total_windows = int(w.item())
     else:
@@ -185,7 +194,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "u64" if k <= 32 else "u128",
-        "data": "synthetic",
+        "data": "synthetic" if not args.rehearse_one_gpu else "synthetic (REHEARSAL: all ranks on one GPU over gloo; not a measurement)",
         "config": {
             "workload": f"synthetic {args.reads} x {L} bp reads per GPU, k={k}, count+canonicalize (insert) "
                         f"+ dump -L 3 threshold, uniform {args.genome} bp genome, seed 20260417",
@@ -193,7 +202,7 @@ def main():
             "windows_per_gpu": windows, "distinct_per_gpu": distinct, "kmers_ge3": int(n_ge3),
             "table_slots": eng.stats()[0],
             "multi_gpu": None if world == 1 else {
-                "job": f"{args.steps} local count steps per rank (no communication), then ONE owner-partitioned "
+                "job": f"{args.steps} local count steps per rank (the rank's synthetic batch each time, no communication), then ONE owner-partitioned "
                        "all-to-all of (key,count) pairs + owner-side sum + global dump -L 3, all inside the timed region",
                 "merge_ms": round(merge_ms, 3), "exchanged_pairs_rank0": merger.last_exchange_pairs,
             },

@@ -174,7 +174,11 @@ class OwnerPartitionedCount:
     all-to-all of (key, count) pairs, owner-side sum."""
 
     def __init__(self, local_ops: TableOps, group=None, device=None, owner_ops: Optional[TableOps] = None,
-                 make_owner_ops=None):
+                 make_owner_ops=None, stage_through_host: bool = False):
+        """``stage_through_host``: run the collectives on CPU copies (a gloo group over GPU
+        engines: rehearsals and tests on a box without one GPU per rank; RCCL takes the device
+        tensors directly)."""
+        self.host = stage_through_host
         self.local = local_ops
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -205,6 +209,8 @@ class OwnerPartitionedCount:
             lo, cnt = lo[order], cnt[order]
             hi = hi[order] if hi is not None else None
             send_counts = torch.bincount(own, minlength=self.world).to(torch.int64)
+        if self.host:
+            send_counts = send_counts.cpu()
         recv_counts = torch.empty_like(send_counts)
         dist.all_to_all_single(recv_counts, send_counts, group=self.group)
         s_list: List[int] = send_counts.tolist()
@@ -213,10 +219,10 @@ class OwnerPartitionedCount:
         self.last_exchange_pairs = int(sum(s_list))
 
         def a2a(t: torch.Tensor) -> torch.Tensor:
-            out = torch.empty(n_recv, dtype=t.dtype, device=t.device)
-            dist.all_to_all_single(out, t.contiguous(), output_split_sizes=r_list, input_split_sizes=s_list,
-                                   group=self.group)
-            return out
+            src = t.contiguous().cpu() if self.host else t.contiguous()
+            out = torch.empty(n_recv, dtype=t.dtype, device=src.device)
+            dist.all_to_all_single(out, src, output_split_sizes=r_list, input_split_sizes=s_list, group=self.group)
+            return out.to(t.device) if self.host else out
 
         rlo = a2a(lo)
         rhi = a2a(hi) if hi is not None else None
@@ -240,7 +246,7 @@ class OwnerPartitionedCount:
         """Exchange the local (key, count) pairs to their owners; returns the global
         number of keys with count >= min_count (``dump -L``)."""
         self.exchange()
-        n = torch.tensor([self.owner.count_ge(min_count)], dtype=torch.int64, device=self.device)
+        n = torch.tensor([self.owner.count_ge(min_count)], dtype=torch.int64, device="cpu" if self.host else self.device)
         if self.world > 1:
             dist.all_reduce(n, op=dist.ReduceOp.SUM, group=self.group)
         return int(n.item())

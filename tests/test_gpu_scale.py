@@ -174,3 +174,69 @@ def test_owner_ordered_dump_matches_owner_of():
         lo = torch.empty(1 << 20, dtype=torch.int64, device=dev); cnt = torch.empty(1 << 20, dtype=torch.int32, device=dev)
         with pytest.raises(KdfError):
             e.export_parts_dev(0, 2, lo.data_ptr(), None, cnt.data_ptr(), 1 << 20)
+
+
+def _two_rank_worker(rank, world, port, k, q):
+    """One rank of test_owner_partitioned_count_two_processes (both share cuda:0; gloo, collectives on host copies)."""
+    import torch
+    import torch.distributed as dist
+    from kmer_denovo_filter_amd import KmerEngine
+    from kmer_denovo_filter_amd.distributed import EngineOps, OwnerPartitionedCount
+    from kmer_denovo_filter_amd.synth import synth_genome, synth_stream
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda:0")
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        g = synth_genome(3_000_000, 11, dev)
+        shards = [synth_stream(150_000, 150, seed=500 + r, device=dev, genome=g) for r in range(world)]
+        torch.cuda.synchronize()
+        with KmerEngine(k, capacity_hint=1 << 27) as le, KmerEngine(k, capacity_hint=1 << 27) as oe:
+            m = OwnerPartitionedCount(EngineOps(le, dev), dist.group.WORLD, dev, owner_ops=EngineOps(oe, dev),
+                                      stage_through_host=True)
+            m.clear()
+            for _ in range(2):                                   # a streamed shard: two batches, one merge
+                m.count_local(shards[rank].packed, shards[rank].invalid, shards[rank].n_bases)
+            assert le.get_stat("log2cap") >= 28                   # the owner-ordered dump is the path taken
+            g5 = m.merge(5)                                       # ONE merge closes the job
+            got = [oe.count_ge(c) for c in (1, 2, 5)] + [g5]      # this rank's share + the global figure
+            owned = oe.stats()[1]
+        if rank == 0:                                            # the same job on one engine
+            with KmerEngine(k, capacity_hint=1 << 27) as e:
+                ops = EngineOps(e, dev)
+                for _ in range(2):
+                    for r in range(world):
+                        ops.count_stream(shards[r].packed, shards[r].invalid, shards[r].n_bases)
+                exp = [e.count_ge(c) for c in (1, 2, 5)]
+            q.put(("ok", got, exp, owned))
+        else:
+            q.put(("ok", got, None, owned))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as ex:  # noqa: BLE001
+        import traceback
+        q.put(("err", f"rank {rank}: {ex}\n{traceback.format_exc()}", None, 0))
+
+
+@pytest.mark.parametrize("k", [31, 47])
+def test_owner_partitioned_count_two_processes(k):
+    """bench.py's N > 1 job with real engines: two PROCESSES (sharing the one GPU of the test box, gloo with
+    host-staged collectives standing in for RCCL) count their shards in two batches, merge once through the
+    owner-ordered device dump, and agree with one engine that counted everything."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, k, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[0] == "ok", r[1]
+    exp = next(r[2] for r in res if r[2] is not None)
+    for i in range(3):
+        assert sum(r[1][i] for r in res) == exp[i], (i, [r[1] for r in res], exp)
+    assert all(r[1][3] == exp[2] for r in res)                                  # merge() returns the global count on every rank
+    assert sum(r[3] for r in res) == exp[0] and all(r[3] > 0 for r in res)     # ownership is exclusive and shared out
