@@ -41,7 +41,7 @@ struct KbPlan {
     uint32_t sub_bits;      // table buckets per partition bucket = 2^sub_bits
     uint32_t log2cap, bucket_bits;
     uint32_t off_stride;    // entries per row of chunk_off = 2^c2 + 1
-    uint32_t dbg;           // experiments only (bucket kernel): 1 skip LDS insert, 2 synthetic keys, 4 skip write-back
+    uint32_t dbg;           // experiments only (bucket kernel, plain-loop variant): 1 skip LDS insert, 4 skip write-back
 };
 
 // device scratch shared by the kernels of one pass
@@ -452,14 +452,14 @@ __device__ __forceinline__ void kb_probe_narrow(uint64_t *tlo, uint32_t *tcnt, u
 // code; the keys that need more go to a wave-private queue in LDS (ballot + mbcnt,
 // no atomics, no barrier) and are probed densely, one per lane, after the batch.
 // Measured on the bench pass: kernel C 7.6 -> 6.5 ms.
-template <int VAR> struct KbVar { static constexpr int LA = 2, QCAP = 1024; };   // lookahead slots; queue entries per workgroup
-#define KB_C_QEXTRA(VAR) (KbVar<VAR>::QCAP * 10 + 16 + (KB_C_RUNS + 4) * 4)
+#define KB_C_LA    2                   // VAR 1: slots of the probe sequence read up front
+#define KB_C_QCAP  1024                // VAR 1: queue entries per workgroup (KB_C_QCAP / 8 per wave)
+#define KB_C_QEXTRA(VAR) ((VAR) ? (KB_C_QCAP * 10 + 16 + (KB_C_RUNS + 4) * 4) : 0)   // LDS bytes VAR 1 adds
 template <int KW, int MODE, int VAR>
 __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
     KbPlan plan, KbScratch s, KdfTable t, KdfCtl *ctl, int table_nonempty)
 {
     constexpr int CHUNK = KbCfg<KW>::CHUNK;
-    constexpr int KB_C_LA = KbVar<VAR>::LA, KB_C_QCAP = KbVar<VAR>::QCAP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t B = 1u << plan.bucket_bits;
     uint64_t *tlo = (uint64_t *)smem;                         // [B]
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
                 while (run_pref[lo_] > ei) --lo_;
                 while (lo_ + 1 < nruns && run_pref[lo_ + 1] <= ei) ++lo_;
                 const unsigned long long src = run_first[lo_] + (ei - run_pref[lo_]);
-                bklo[q] = (plan.dbg & 2) ? ((src * 0x9E3779B97F4A7C15ull) >> 2) : s.ent_lo[src];
+                bklo[q] = s.ent_lo[src];
                 if constexpr (KW == 2) bkhi[q] = s.ent_hi[src];
             }
           }
