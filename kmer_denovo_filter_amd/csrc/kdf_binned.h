@@ -107,6 +107,7 @@ struct KbWindows {
     // the raw words into e[] / valid.  The compiler places the vmcnt wait at the
     // first USE, i.e. in finish().
     uint64_t raw[NE + 1], m0, m1;
+    uint64_t g0, g1;      // narrow keys: the span with its 2-bit groups reversed, pre-shifted (forward k-mers)
     int p0_;
     bool in_range;
     __device__ __forceinline__ void issue(const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid,
@@ -129,6 +130,16 @@ struct KbWindows {
         for (int i = 0; i < NE; ++i) e[i] = kdf_funnel(raw[i], raw[i + 1], sh);
         const uint64_t v = kdf_valid_windows(m0, m1, k);
         valid = in_range ? (uint32_t)((v >> p0_) & ((1ull << WPT) - 1)) : 0u;
+        if constexpr (KW == 1) {
+            // Forward k-mer of window u (MSB-first code) = bits [2(64-u-k), +2k) of F, the
+            // 128-bit span with its 2-bit groups reversed: ONE reversal per thread instead of
+            // one per window.  F is pre-shifted by the runtime part of that offset so that
+            // key(u) shifts by the compile-time 2(WPT-1-u).
+            const uint64_t fhi = kdf_rev2(e[0]), flo = kdf_rev2(e[1]);
+            const int base = 2 * (64 - k - (WPT - 1));             // 34 (k = 32) .. 118
+            g0 = base >= 64 ? (fhi >> (base - 64)) : kdf_funnel(flo, fhi, base);
+            g1 = base >= 64 ? 0ull : (fhi >> base);
+        }
     }
     __device__ __forceinline__ void load(const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid,
                                          uint64_t tile, uint64_t n_tiles, int part, int k_) {
@@ -137,7 +148,9 @@ struct KbWindows {
     }
     __device__ __forceinline__ void key(int u, uint64_t &lo, uint64_t &hi) const {   // u: compile-time
         if constexpr (KW == 1) {
-            lo = kdf_canon_narrow(kdf_funnel(e[0], e[1], 2 * u), k, kmask); hi = 0;
+            const uint64_t rc = ~kdf_funnel(e[0], e[1], 2 * u) & kmask;      // reverse complement: ~E (kdf_device.h)
+            const uint64_t fwd = kdf_funnel(g0, g1, 2 * (WPT - 1 - u)) & kmask;
+            lo = fwd < rc ? fwd : rc; hi = 0;
         } else {
             kdf_canon_wide(kdf_funnel(e[0], e[1], 2 * u), kdf_funnel(e[1], e[2], 2 * u), k, lo, hi);
         }
