@@ -80,7 +80,8 @@ int kdf_stats(kdf_engine *h, uint64_t *capacity, uint64_t *distinct, uint64_t *w
 /* Tuning knobs and counters (tests force either kernel path through these):
  *   options  "force_path" 0 auto / 1 direct global-table kernels / 2 binned
  *            LDS-bucket pipeline; "binned_min_positions" (stream positions from
- *            which count calls take the binned path); "binned_filtered_min_log2cap"
+ *            which count calls take the binned path); "binned_max_positions" (positions per
+ *            binned pass, <= 2^31: longer streams take several passes); "binned_filtered_min_log2cap"
  *   stats    "binned_passes", "replayed_buckets", "log2cap", "bucket_bits" */
 int kdf_set_option(kdf_engine *h, const char *name, int64_t value);
 int kdf_get_stat(kdf_engine *h, const char *name, int64_t *value);

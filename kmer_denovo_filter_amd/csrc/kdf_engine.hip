@@ -253,6 +253,8 @@ struct kdf_engine {
     void *kb_buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ent_lo, ent_hi, chunk_off, failed, hist_wg, wg_base
     size_t kb_bytes[6] = {0, 0, 0, 0, 0, 0};
     uint64_t opt_binned_min_positions = 1ull << 22;  // smaller batches use the direct global-table kernels
+    uint64_t opt_binned_max_positions = 1ull << 31;  // longer streams are walked in several binned passes: a pass must add
+                                                     // < 2^32 to any slot (kernel C saturates by comparing with the HBM count)
     uint32_t opt_binned_filtered_min_log2cap = 23;   // count --if goes binned from 2^23 slots (measured crossover)
     int opt_force_path = 0;                          // 0 auto, 1 direct, 2 binned
     uint32_t opt_debug_flags = 0;                    // experiments only (KbPlan::dbg)
@@ -484,6 +486,25 @@ static int kb_set_lds_attrs(kdf_engine *h, size_t a1, size_t b, size_t c) {
 }
 
 static int table_rehash(kdf_engine *h, uint32_t new_log2);
+template <int KW>
+static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases, bool filtered);
+
+// the binned path over a stream of any length: passes of at most opt_binned_max_positions
+// positions, each starting on a tile boundary (windows that start in a pass may read on
+// into the next tiles: the stream is one buffer)
+static int kb_passes(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases, bool filtered) {
+    const uint64_t step = h->opt_binned_max_positions;
+    for (uint64_t off = 0; off < n_bases; off += step) {
+        const uint64_t len = std::min<uint64_t>(step, n_bases - off);
+        const uint64_t *p = d_packed + off / 32, *m = d_invalid + off / 64;
+        int rc = h->kw == 1 ? kb_pass<1>(h, p, m, len, filtered) : kb_pass<2>(h, p, m, len, filtered);
+        if (rc) return rc;
+        if (!filtered && off + step < n_bases)                 // room for the next pass (as count_insert_dev does after the last)
+            while (h->distinct * 10 > h->cap * 7)
+                if ((rc = table_rehash(h, h->t.log2cap + 1))) return rc;
+    }
+    return KDF_OK;
+}
 
 // one pass of the binned pipeline over a device-resident stream
 template <int KW>
@@ -609,8 +630,7 @@ static int count_insert_dev(kdf_engine *h, const uint64_t *d_packed, const uint6
     if (h->filter_mode) return fail(h, KDF_ERR_STATE, "kdf_count_reads: a filter is loaded; call kdf_clear first");
     const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
     if (use_binned(h, n_bases, false)) {
-        int rc = h->kw == 1 ? kb_pass<1>(h, d_packed, d_invalid, n_bases, false)
-                            : kb_pass<2>(h, d_packed, d_invalid, n_bases, false);
+        int rc = kb_passes(h, d_packed, d_invalid, n_bases, false);
         if (rc) return rc;
         // keep the load <= 0.7 for the next batch (a 2048-slot bucket then holds
         // 1434 +- 38 keys: overflow, which is handled anyway, stays a rare event)
@@ -646,9 +666,7 @@ static int count_filtered_dev(kdf_engine *h, const uint64_t *d_packed, const uin
     const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
     if (n_tiles == 0) return KDF_OK;
     { int rc0 = materialize(h); if (rc0) return rc0; }
-    if (use_binned(h, n_bases, true))
-        return h->kw == 1 ? kb_pass<1>(h, d_packed, d_invalid, n_bases, true)
-                          : kb_pass<2>(h, d_packed, d_invalid, n_bases, true);
+    if (use_binned(h, n_bases, true)) return kb_passes(h, d_packed, d_invalid, n_bases, true);
     launch_stream<MODE_FILTERED>(h, d_packed, d_invalid, 0, n_tiles, nullptr);
     HIPCHK(h, hipGetLastError());
     return KDF_OK;
@@ -1173,6 +1191,10 @@ int kdf_set_option(kdf_engine *h, const char *name, int64_t value) {
     if (!h || !name) return fail(h, KDF_ERR_INVALID, "kdf_set_option: NULL argument");
     const std::string n(name);
     if (n == "binned_min_positions") h->opt_binned_min_positions = (uint64_t)value;
+    else if (n == "binned_max_positions") {
+        if (value < KDF_TILE || value > (1ll << 31)) return fail(h, KDF_ERR_INVALID, "binned_max_positions must be in [64, 2^31]");
+        h->opt_binned_max_positions = (uint64_t)value / KDF_TILE * KDF_TILE;      // passes start on tile boundaries
+    }
     else if (n == "binned_filtered_min_log2cap") h->opt_binned_filtered_min_log2cap = (uint32_t)value;
     else if (n == "force_path") h->opt_force_path = (int)value;
     else if (n == "debug_flags") h->opt_debug_flags = (uint32_t)value;

@@ -189,3 +189,58 @@ def test_binned_skewed_multiplicity(oracle):
         np.testing.assert_array_equal(glo, lo)
         np.testing.assert_array_equal(gcnt, cnt)
         assert int(gcnt.max()) == 400 * 270
+
+
+@pytest.mark.parametrize("k", [31, 45])
+def test_binned_stream_walked_in_several_passes(oracle, k):
+    """A stream longer than a binned pass may cover (2^31 positions by default; 8192 here) is
+    walked pass by pass, each starting on a tile boundary: windows that start in one pass and
+    end in the next are counted exactly once, insert mode and count --if."""
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    rng = np.random.default_rng(12)
+    genome = rng.integers(0, 4, 30_000).astype(np.uint8)
+    reads = rand_reads(rng, 600, 60, 260, genome=genome)
+    st = ReadStream.from_strings(reads)
+    t, (lo, hi, cnt) = oracle_sorted(oracle, k, reads)
+    with KmerEngine(k, capacity_hint=1 << 15) as e:
+        e.set_option("force_path", 2); e.set_option("binned_max_positions", 8192)
+        e.count(st)
+        assert e.get_stat("binned_passes") == -(-st.n_bases // 8192) > 5
+        glo, ghi, gcnt = e.export_ge(0)
+        np.testing.assert_array_equal(glo, lo); np.testing.assert_array_equal(ghi, hi); np.testing.assert_array_equal(gcnt, cnt)
+    sel = slice(0, len(lo), 3)
+    ot = oracle.OracleTable(k, 1 << 12).load_filter(lo[sel], hi[sel]).count_reads_filtered(reads)
+    with KmerEngine(k, capacity_hint=1 << 15) as e:
+        e.load_filter(lo[sel], hi[sel] if k > 32 else None)
+        e.set_option("force_path", 2); e.set_option("binned_max_positions", 8192)
+        e.count_filtered(st)
+        np.testing.assert_array_equal(e.query(lo[sel], hi[sel] if k > 32 else None), ot.query(lo[sel], hi[sel]))
+        with pytest.raises(Exception):
+            e.set_option("binned_max_positions", 1 << 40)
+
+
+@pytest.mark.parametrize("k,path", [(31, 1), (31, 2), (45, 1), (45, 2)])
+def test_counts_saturate_at_uint32_max(oracle, k, path):
+    """Jellyfish's 4-byte counter: a count that would pass 2^32 - 1 stays there, in the direct
+    kernels (atomic add + max) and in kernel C (wrapping LDS adds, saturated at write-back by
+    comparing with the HBM count) -- both probe variants of C, narrow and wide keys."""
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    rng = np.random.default_rng(3)
+    reads = ["A" * 200] * 50 + rand_reads(rng, 300, 80, 160)
+    st = ReadStream.from_strings(reads)
+    t, (lo, hi, cnt) = oracle_sorted(oracle, k, reads)
+    a_idx = int(np.flatnonzero((lo == 0) & (hi == 0))[0])                      # poly-A is key 0
+    n_a = int(cnt[a_idx]); assert n_a == 50 * (200 - k + 1)
+    other = (a_idx + 1) % len(lo)
+    for flags in ((0,) if path == 1 or k > 32 else (0, 8)):                      # 8: kernel C's plain probe loop
+        with KmerEngine(k, capacity_hint=1 << 14) as e:
+            e.set_option("force_path", path); e.set_option("debug_flags", flags)
+            pre = np.array([0xFFFFFFFF - n_a + 7, 0xFFFFFFF0], np.uint32)          # 7 short of saturating; already near the top
+            e.add_pairs(np.array([lo[a_idx], lo[other]]), np.array([hi[a_idx], hi[other]]), pre)
+            e.count(st)
+            got = e.query(np.array([lo[a_idx], lo[other]]), np.array([hi[a_idx], hi[other]]) if k > 32 else None)
+            assert int(got[0]) == 0xFFFFFFFF, hex(int(got[0]))
+            assert int(got[1]) == min(0xFFFFFFFF, 0xFFFFFFF0 + int(cnt[other]))
+            glo, ghi, gcnt = e.export_ge(0)
+            exp = cnt.astype(np.uint64).copy(); exp[a_idx] += int(pre[0]); exp[other] += int(pre[1])
+            np.testing.assert_array_equal(gcnt, np.minimum(exp, 0xFFFFFFFF).astype(np.uint32))
