@@ -114,6 +114,25 @@ struct StreamWriter {
         }
         for (; i < len; ++i) put(kCode.t[(uint8_t)a[i]]);
     }
+    // npos positions of another stream (arrays with >= 1 word of slack after the last used word) from its position sp
+    void append_stream(const uint64_t *sp_packed, const uint64_t *sp_invalid, uint64_t sp, uint64_t npos) {
+        auto copy = [](uint64_t *dst, uint64_t db, const uint64_t *src, uint64_t sb, uint64_t nbits) {
+            while (nbits) {
+                const int take = nbits < 64 ? (int)nbits : 64;
+                const uint64_t sw = sb >> 6; const int ss = (int)(sb & 63);
+                uint64_t v = src[sw] >> ss;
+                if (ss) v |= src[sw + 1] << (64 - ss);
+                if (take < 64) v &= (1ull << take) - 1;
+                const uint64_t dw = db >> 6; const int ds = (int)(db & 63);
+                dst[dw] |= v << ds;
+                if (ds && ds + take > 64) dst[dw + 1] |= v >> (64 - ds);
+                sb += take; db += take; nbits -= take;
+            }
+        };
+        copy(packed, 2 * n, sp_packed, 2 * sp, 2 * npos);
+        copy(invalid, n, sp_invalid, sp, npos);
+        n += npos;
+    }
     void finish() {
         if (n & 63) invalid[n >> 6] |= ~0ull << (n & 63);
         const uint64_t first = (n + 63) >> 6;
@@ -215,10 +234,13 @@ struct BgzfPool {
         for (int i = 0; i < nthreads; ++i) workers.emplace_back([this] { work_loop(); });
     }
     ~BgzfPool() {
-        { std::lock_guard<std::mutex> g(mu); stop = true; }
-        cv_work.notify_all(); cv_free.notify_all(); cv_done.notify_all();
+        shutdown();
         if (io.joinable()) io.join();
         for (auto &t : workers) if (t.joinable()) t.join();
+    }
+    void shutdown() {
+        { std::lock_guard<std::mutex> g(mu); stop = true; }
+        cv_work.notify_all(); cv_free.notify_all(); cv_done.notify_all();
     }
     void io_loop() {
         for (;;) {
@@ -259,7 +281,8 @@ struct BgzfPool {
     // append the next block's bytes to `out`.  0 ok, 1 eof, -1 error (msg in err)
     int next(std::vector<uint8_t> &out, std::string &err) {
         std::unique_lock<std::mutex> lk(mu);
-        cv_done.wait(lk, [this] { return (head < tail && ring[head % ring.size()].state >= 2) || (eof_read && head == tail); });
+        cv_done.wait(lk, [this] { return stop || (head < tail && ring[head % ring.size()].state >= 2) || (eof_read && head == tail); });
+        if (stop) return 1;
         if (head == tail) {
             if (io_error) { err = io_err; return -1; }
             return 1;
@@ -277,12 +300,53 @@ struct BgzfPool {
 };
 
 
+// ---- parallel record parsing ---------------------------------------------------
+// With threads > 1 (and no alignment details wanted) the single parser thread is the
+// bottleneck once BGZF inflation is spread over a pool (~0.25 us per record).  A chunker
+// thread cuts the inflated byte stream into chunks of whole records (on QNAME-run
+// boundaries when runs are collapsed, so every chunk is self-contained), worker threads
+// turn chunks into chunk-local packed streams + metadata, and kdf_reader_next appends
+// those, in order, to the caller's batch with bit-shifted word copies.
+struct RawChunk { std::vector<uint8_t> bytes; uint64_t first_ordinal = 0; };
+struct ParsedChunk {
+    std::vector<uint64_t> packed, invalid;        // chunk-local stream, bit 0 = first base
+    std::vector<int64_t> off;                     // n + 1 positions
+    std::vector<uint16_t> flags; std::vector<int32_t> ref, pos;
+    std::string names; std::vector<int64_t> name_off; std::vector<uint64_t> ordinal;
+    size_t next = 0;                              // consumer cursor (records)
+    std::string err;
+    size_t n() const { return flags.size(); }
+};
+struct kdf_reader;
+struct ParsePipe {
+    kdf_reader *r;
+    std::vector<RawChunk> raw; std::vector<ParsedChunk> out; std::vector<int> state;   // 0 free, 1 raw, 2 parsed
+    size_t head = 0, tail = 0;                    // consumer / chunker sequence numbers
+    std::deque<size_t> work;
+    bool stop = false, eof = false;
+    std::string err;                              // chunker error (reported after the chunks before it)
+    std::mutex mu;
+    std::condition_variable cv_free, cv_work, cv_done;
+    std::thread chunker;
+    std::vector<std::thread> workers;
+    ParsePipe(kdf_reader *reader, int nthreads);
+    ~ParsePipe();
+    void chunk_loop();
+    void work_loop();
+    void parse(const RawChunk &in, ParsedChunk &o) const;
+    ParsedChunk *front(std::string &e);           // next parsed chunk in order; nullptr at end of file or on error (e set)
+    void pop();
+};
+
 struct kdf_reader {
     enum Kind { BAM, FASTA } kind = BAM;
     std::string err;
     // ---- BAM
     FILE *fp = nullptr;
     std::unique_ptr<BgzfPool> pool;    // threaded inflate (threads > 1)
+    std::unique_ptr<ParsePipe> pipe;   // threaded record parsing (threads > 1, no alignment details)
+    int threads = 1;
+    bool started = false;              // first kdf_reader_next seen (the parsing mode is fixed then)
     BgzfBlock blk;                     // synchronous inflate (threads <= 1)
     std::vector<uint8_t> inbuf;        // decompressed, not yet consumed
     size_t inpos = 0;
@@ -523,6 +587,165 @@ void fasta_fill(kdf_reader *r, size_t want) {
 
 }  // namespace
 
+
+// ---- parallel record parsing: implementation ----------------------------------
+
+ParsePipe::ParsePipe(kdf_reader *reader, int nthreads) : r(reader) {
+    const size_t ring = (size_t)nthreads * 2 + 2;
+    raw.resize(ring); out.resize(ring); state.assign(ring, 0);
+    chunker = std::thread([this] { chunk_loop(); });
+    for (int i = 0; i < nthreads; ++i) workers.emplace_back([this] { work_loop(); });
+}
+
+ParsePipe::~ParsePipe() {
+    { std::lock_guard<std::mutex> g(mu); stop = true; }
+    cv_free.notify_all(); cv_work.notify_all(); cv_done.notify_all();
+    if (chunker.joinable()) chunker.join();
+    for (auto &t : workers) if (t.joinable()) t.join();
+}
+
+// Cuts the inflated stream into chunks of whole records.  With QNAME collapsing a chunk
+// ends only where the next KEPT record starts a new name run (records dropped by the flag
+// filter do not break a run: bam_pump skips them before the run logic).
+void ParsePipe::chunk_loop() {
+    constexpr size_t TARGET_RECORDS = 2048;
+    std::string prev_name; bool have_prev = false;
+    for (;;) {
+        size_t slot;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_free.wait(lk, [this] { return stop || tail - head < raw.size(); });
+            if (stop) return;
+            slot = tail % raw.size();
+        }
+        RawChunk &c = raw[slot];
+        c.first_ordinal = r->n_records;
+        // the chunk is scanned in place (r->inpos stays at its first byte, so the buffer's
+        // compaction never drops unread chunk bytes) and copied out with ONE memcpy
+        size_t nrec = 0, rel = 0; bool end = false; std::string e;        // rel: scan offset from r->inpos (which compaction may reset)
+        for (;;) {
+            bool er;
+            if (!bam_need(r, rel + 4, &er)) { end = true; if (er) e = r->err; break; }
+            const int32_t bs = le32(r->inbuf.data() + r->inpos + rel);
+            if (bs < 32) { end = true; e = "corrupt BAM record"; break; }
+            if (!bam_need(r, rel + 4 + (size_t)bs, &er)) { end = true; e = er ? r->err : std::string("truncated BAM record"); break; }
+            const uint8_t *p = r->inbuf.data() + r->inpos + rel + 4;      // (bam_need may have moved or compacted the buffer)
+            const unsigned l_rn = p[8];
+            const uint16_t flag = (uint16_t)(p[14] | (p[15] << 8));
+            const bool kept = !(flag & r->flag_off);
+            bool boundary = true;                               // may the chunk end before this record?
+            if (r->collapse && kept) {
+                const size_t nl = l_rn ? l_rn - 1 : 0;
+                if (32 + (size_t)l_rn > (size_t)bs) { end = true; e = "corrupt BAM record (field sizes)"; break; }
+                boundary = !have_prev || prev_name.size() != nl || memcmp(prev_name.data(), p + 32, nl) != 0;
+            } else if (r->collapse) {
+                boundary = false;                               // a dropped record inside a run does not end it
+            }
+            if (nrec >= TARGET_RECORDS && boundary) break;      // this record opens the next chunk
+            if (r->collapse && kept && boundary) { prev_name.assign((const char *)p + 32, l_rn ? l_rn - 1 : 0); have_prev = true; }
+            rel += 4 + (size_t)bs;
+            ++nrec;
+        }
+        c.bytes.assign(r->inbuf.begin() + (long)r->inpos, r->inbuf.begin() + (long)(r->inpos + rel));
+        r->inpos += rel;
+        r->n_records += nrec;
+        std::lock_guard<std::mutex> g(mu);
+        if (nrec) { state[slot] = 1; work.push_back(tail); ++tail; cv_work.notify_one(); }
+        if (end) { eof = true; err = e; cv_done.notify_all(); return; }
+    }
+}
+
+void ParsePipe::work_loop() {
+    for (;;) {
+        size_t seq;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_work.wait(lk, [this] { return stop || !work.empty(); });
+            if (stop) return;
+            seq = work.front(); work.pop_front();
+        }
+        const size_t slot = seq % raw.size();
+        parse(raw[slot], out[slot]);
+        std::lock_guard<std::mutex> g(mu);
+        state[slot] = 2;
+        cv_done.notify_all();
+    }
+}
+
+// bam_next_raw + bam_pump + the emit part of kdf_reader_next, on one chunk, without copying records
+void ParsePipe::parse(const RawChunk &in, ParsedChunk &o) const {
+    o.off.clear(); o.flags.clear(); o.ref.clear(); o.pos.clear(); o.names.clear(); o.name_off.clear(); o.ordinal.clear();
+    o.next = 0; o.err.clear();
+    // every record carries >= (l_seq + 1) / 2 sequence bytes: positions <= 2 * bytes + records <= 2.1 * bytes
+    const size_t max_pos = in.bytes.size() * 2 + in.bytes.size() / 16 + 64;
+    o.packed.assign(max_pos / 32 + 4, 0); o.invalid.assign(max_pos / 64 + 4, 0);
+    StreamWriter w(o.packed.data(), o.invalid.data());
+    struct Ref { const uint8_t *p; int32_t bs; uint64_t ordinal; };
+    auto emit = [&](const Ref &x) {
+        const uint8_t *p = x.p;
+        const unsigned l_rn = p[8], n_cig = p[12] | (p[13] << 8);
+        const int32_t l_seq = le32(p + 16);
+        o.off.push_back((int64_t)w.n);
+        w.put_seq4(p + 32 + l_rn + 4 * n_cig, l_seq);
+        w.put_sep();
+        o.flags.push_back((uint16_t)(p[14] | (p[15] << 8))); o.ref.push_back(le32(p)); o.pos.push_back(le32(p + 4));
+        o.name_off.push_back((int64_t)o.names.size());
+        o.names.append((const char *)p + 32, l_rn ? l_rn - 1 : 0); o.names.push_back('\0');
+        o.ordinal.push_back(x.ordinal);
+    };
+    Ref best[3]; int score[3] = {-1, -1, -1};
+    const uint8_t *run_name = nullptr; size_t run_len = 0; bool have_run = false;
+    auto flush = [&]() {
+        for (int i = 0; i < 3; ++i) if (score[i] >= 0) { emit(best[i]); score[i] = -1; }
+        have_run = false;
+    };
+    const uint8_t *q = in.bytes.data(), *end = q + in.bytes.size();
+    uint64_t ordinal = in.first_ordinal;
+    while (q < end) {
+        const int32_t bs = le32(q);
+        const uint8_t *p = q + 4;
+        q += 4 + (size_t)bs;
+        const uint64_t my = ordinal++;
+        const unsigned l_rn = p[8], n_cig = p[12] | (p[13] << 8);
+        const uint16_t flag = (uint16_t)(p[14] | (p[15] << 8));
+        const int32_t l_seq = le32(p + 16);
+        const size_t need = 32 + l_rn + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+        if (l_seq < 0 || need > (size_t)bs) { o.err = "corrupt BAM record (field sizes)"; return; }
+        if (flag & r->flag_off) continue;
+        const Ref me{p, bs, my};
+        if (!r->collapse) { emit(me); continue; }
+        const size_t nl = l_rn ? l_rn - 1 : 0;
+        if (!have_run || run_len != nl || memcmp(run_name, p + 32, nl) != 0) {
+            if (have_run) flush();
+            run_name = p + 32; run_len = nl; have_run = true;
+        }
+        const bool r1 = flag & 0x40, r2 = flag & 0x80;
+        const int part = (r1 && !r2) ? 1 : (r2 && !r1) ? 2 : 0;
+        const uint8_t *sq = p + 32 + l_rn + 4 * n_cig;
+        const int sc = (l_seq > 0 && sq[((size_t)l_seq + 1) / 2] != 0xFF) ? 2 : 1;
+        if (sc > score[part]) { best[part] = me; score[part] = sc; }
+    }
+    if (have_run) flush();
+    o.off.push_back((int64_t)w.n);
+}
+
+ParsedChunk *ParsePipe::front(std::string &e) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [this] { return stop || (head < tail && state[head % raw.size()] == 2) || (eof && head == tail); });
+    if (stop) { e = "reader closed"; return nullptr; }
+    if (head == tail) { e = err; return nullptr; }           // end of file (err empty) or the chunker's error
+    ParsedChunk &c = out[head % raw.size()];
+    if (!c.err.empty()) { e = c.err; return nullptr; }
+    return &c;
+}
+
+void ParsePipe::pop() {
+    std::lock_guard<std::mutex> g(mu);
+    state[head % raw.size()] = 0;
+    ++head;
+    cv_free.notify_one();
+}
+
 extern "C" {
 
 void kdf_stream_words(uint64_t n_bases, uint64_t *packed_words, uint64_t *mask_words) {
@@ -574,7 +797,8 @@ int kdf_bam_open(const char *path, uint32_t flag_off, int collapse, int threads,
     if (!r->fp) { rfail(nullptr, KDF_ERR_IO, "cannot open %s", path); delete r; return KDF_ERR_IO; }
     static const size_t kBuf = 1 << 20;
     setvbuf(r->fp, nullptr, _IOFBF, kBuf);
-    if (threads > 1) r->pool.reset(new BgzfPool(r->fp, std::min(threads, 64)));
+    r->threads = std::min(threads, 64);
+    if (threads > 1) r->pool.reset(new BgzfPool(r->fp, r->threads));
     int rc = bam_read_header(r);
     if (rc) { g_host_err = std::string(path) + ": " + r->err; kdf_reader_close(r); return rc; }
     *out = r;
@@ -596,6 +820,8 @@ int kdf_fasta_open(const char *path, int k, kdf_reader **out) {
 
 void kdf_reader_close(kdf_reader *r) {
     if (!r) return;
+    if (r->pool) r->pool->shutdown();  // unblocks a chunker waiting for inflated bytes
+    r->pipe.reset();                   // joins the chunker and parser threads
     r->pool.reset();                   // joins the I/O and inflate threads before the file closes
     if (r->fp) fclose(r->fp);
     if (r->gz) gzclose(r->gz);
@@ -613,7 +839,47 @@ int kdf_reader_next(kdf_reader *r, uint64_t max_bases, int64_t max_reads, uint64
     StreamWriter w(packed_out, invalid_out);
     w.begin(max_bases);
     int64_t n = 0;
-    if (r->kind == kdf_reader::BAM) {
+    if (r->kind == kdf_reader::BAM && !r->started) {
+        r->started = true;
+        // inflate takes ~60 % of the CPU time of a pass, parsing ~40 %: half as many parser threads
+        if (r->pool && !r->want_aux) r->pipe.reset(new ParsePipe(r, std::max(2, (r->threads + 1) / 2)));
+    }
+    if (r->kind == kdf_reader::BAM && r->pipe) {
+        // parallel parsing: append whole records of the parsed chunks, in file order
+        while (n < max_reads) {
+            std::string e;
+            ParsedChunk *c = r->pipe->front(e);
+            if (!c) { if (!e.empty()) return rfail(r, KDF_ERR_IO, "%s", e.c_str()); break; }
+            const size_t nr = c->n();
+            if (c->next < nr) {
+                const size_t i = c->next;
+                const uint64_t first_len = (uint64_t)(c->off[i + 1] - c->off[i]);
+                if (first_len > max_bases)
+                    return rfail(r, KDF_ERR_INVALID, "read %s (%llu bases) exceeds max_bases", c->names.c_str() + c->name_off[i],
+                                 (unsigned long long)(first_len - 1));
+                const uint64_t room = max_bases - w.n;
+                if (first_len > room) break;
+                // largest j with off[j] - off[i] <= room and j - i <= max_reads - n
+                size_t j = std::min(nr, i + (size_t)(max_reads - n));
+                if ((uint64_t)(c->off[j] - c->off[i]) > room)
+                    j = (size_t)(std::upper_bound(c->off.begin() + (long)i, c->off.begin() + (long)j + 1, c->off[i] + (int64_t)room) - c->off.begin()) - 1;
+                const int64_t base = (int64_t)w.n - c->off[i];
+                if (stream_offsets_out) for (size_t t = i; t < j; ++t) stream_offsets_out[n + (int64_t)(t - i)] = c->off[t] + base;
+                w.append_stream(c->packed.data(), c->invalid.data(), (uint64_t)c->off[i], (uint64_t)(c->off[j] - c->off[i]));
+                r->m_flags.insert(r->m_flags.end(), c->flags.begin() + (long)i, c->flags.begin() + (long)j);
+                r->m_ref.insert(r->m_ref.end(), c->ref.begin() + (long)i, c->ref.begin() + (long)j);
+                r->m_pos.insert(r->m_pos.end(), c->pos.begin() + (long)i, c->pos.begin() + (long)j);
+                r->m_ordinal.insert(r->m_ordinal.end(), c->ordinal.begin() + (long)i, c->ordinal.begin() + (long)j);
+                const int64_t nb0 = c->name_off[i], nb1 = j < nr ? c->name_off[j] : (int64_t)c->names.size();
+                const int64_t shift = (int64_t)r->m_names.size() - nb0;
+                for (size_t t = i; t < j; ++t) r->m_name_off.push_back(c->name_off[t] + shift);
+                r->m_names.append(c->names, (size_t)nb0, (size_t)(nb1 - nb0));
+                n += (int64_t)(j - i);
+                c->next = j;
+            }
+            if (c->next == nr) r->pipe->pop(); else break;     // the batch is full
+        }
+    } else if (r->kind == kdf_reader::BAM) {
         while (n < max_reads) {
             if (bam_pump(r) < 0) return KDF_ERR_IO;
             if (r->ready.empty()) break;
@@ -703,6 +969,7 @@ int kdf_reader_last_meta(kdf_reader *r, const uint16_t **flags, const int32_t **
 
 int kdf_reader_want_aux(kdf_reader *r, int enable) {
     if (!r || r->kind != kdf_reader::BAM) return KDF_ERR_INVALID;
+    if (r->started) return rfail(r, KDF_ERR_STATE, "kdf_reader_want_aux: call it before the first kdf_reader_next");
     r->want_aux = enable != 0;
     return KDF_OK;
 }
