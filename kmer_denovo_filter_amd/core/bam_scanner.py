@@ -15,6 +15,7 @@ post-processing is the next scope row.
 """
 from __future__ import annotations
 
+import os
 import logging
 from dataclasses import dataclass, field
 from typing import Iterator, List, Optional, Set, Tuple
@@ -32,6 +33,8 @@ logger = logging.getLogger(__name__)
 # stream positions per scan launch (the reference batches 5000 reads per query,
 # core/bam_scanner.py:247; batch size does not change results)
 SCAN_BATCH_BASES = 1 << 26
+# host threads of the BAM feeder (BGZF inflate + record parsing); the reference scans contigs in a process pool
+READER_THREADS = max(1, min(8, os.cpu_count() or 1))
 
 _worker_engine: Optional[KmerEngine] = None
 _worker_kmer_size: Optional[int] = None
@@ -90,7 +93,7 @@ def scan_bam_for_hits(child_bam, engine: Optional[KmerEngine] = None, min_dk_per
         raise RuntimeError("scan worker not initialised (_init_scan_worker)")
     min_dk = _worker_min_distinct_kmers_per_read if min_dk_per_read is None else min_dk_per_read
     with bam_reader(child_bam, flag_off=FLAG_OFF_MODULE3, collapse=False, max_bases=batch_bases,
-                    max_reads=1 << 20, want_meta=True) as rd:
+                    max_reads=1 << 20, threads=READER_THREADS, want_meta=True) as rd:
         for batch in rd:
             try:
                 hits, distinct = eng.scan(batch)
@@ -249,7 +252,7 @@ def scan_bam_module3(child_bam, kmer_size=None, min_dk_per_read=None, engine=Non
     per_task = collections.OrderedDict()        # ref_id -> list of informative record dicts, file order
     total_scanned = 0
     rd = bam_reader(child_bam, flag_off=FLAG_OFF_MODULE3, collapse=False, max_bases=batch_bases,
-                    max_reads=1 << 20, want_aux=True)
+                    max_reads=1 << 20, threads=READER_THREADS, want_aux=True)
     refs = rd.references()
     with rd:
         for batch in rd:

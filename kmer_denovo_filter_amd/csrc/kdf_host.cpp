@@ -313,6 +313,11 @@ struct ParsedChunk {
     std::vector<int64_t> off;                     // n + 1 positions
     std::vector<uint16_t> flags; std::vector<int32_t> ref, pos;
     std::string names; std::vector<int64_t> name_off; std::vector<uint64_t> ordinal;
+    // alignment details (kdf_reader_want_aux)
+    std::vector<uint32_t> cigar; std::vector<int64_t> cigar_off;      // n + 1
+    std::string sa; std::vector<int64_t> sa_off;                      // n; -1 = no SA tag
+    std::vector<uint8_t> qual; std::vector<int64_t> qual_off;         // n + 1
+    std::vector<uint8_t> mapq;
     size_t next = 0;                              // consumer cursor (records)
     std::string err;
     size_t n() const { return flags.size(); }
@@ -466,6 +471,33 @@ int bam_read_header(kdf_reader *r) {
     return KDF_OK;
 }
 
+// walk the optional fields [a, end) for SA:Z; true + value (not NUL-terminated) when present
+bool bam_find_sa(const uint8_t *a, const uint8_t *end, const char **val, size_t *len) {
+    while (a + 3 <= end) {
+        const char t0 = (char)a[0], t1 = (char)a[1], ty = (char)a[2];
+        a += 3;
+        size_t n = 0;
+        if (ty == 'A' || ty == 'c' || ty == 'C') n = 1;
+        else if (ty == 's' || ty == 'S') n = 2;
+        else if (ty == 'i' || ty == 'I' || ty == 'f') n = 4;
+        else if (ty == 'Z' || ty == 'H') {
+            const uint8_t *z = a;
+            while (z < end && *z) ++z;
+            if (t0 == 'S' && t1 == 'A' && ty == 'Z') { *val = (const char *)a; *len = (size_t)(z - a); return true; }
+            n = (size_t)(z - a) + 1;
+        } else if (ty == 'B') {
+            if (a + 5 > end) break;
+            const char sub = (char)a[0];
+            const uint32_t cnt = (uint32_t)le32(a + 1);
+            const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+            n = 5 + es * (size_t)cnt;
+        } else break;                                       // unknown type: stop parsing
+        if (a + n > end) break;
+        a += n;
+    }
+    return false;
+}
+
 // parse the next raw alignment; returns 1 at EOF, 0 ok, <0 error.
 int bam_next_raw(kdf_reader *r, Record &rec, bool &has_qual) {
     bool e;
@@ -497,30 +529,8 @@ int bam_next_raw(kdf_reader *r, Record &rec, bool &has_qual) {
         const uint8_t *cg = p + 32 + l_rn;
         rec.cigar.resize(n_cig);
         for (unsigned i = 0; i < n_cig; ++i) rec.cigar[i] = (uint32_t)le32(cg + 4 * i);
-        // walk the optional fields for SA:Z
-        const uint8_t *a = p + need, *end = p + bs;
-        while (a + 3 <= end) {
-            const char t0 = (char)a[0], t1 = (char)a[1], ty = (char)a[2];
-            a += 3;
-            size_t len = 0;
-            if (ty == 'A' || ty == 'c' || ty == 'C') len = 1;
-            else if (ty == 's' || ty == 'S') len = 2;
-            else if (ty == 'i' || ty == 'I' || ty == 'f') len = 4;
-            else if (ty == 'Z' || ty == 'H') {
-                const uint8_t *z = a;
-                while (z < end && *z) ++z;
-                if (t0 == 'S' && t1 == 'A' && ty == 'Z') { rec.sa.assign((const char *)a, (size_t)(z - a)); rec.has_sa = true; }
-                len = (size_t)(z - a) + 1;
-            } else if (ty == 'B') {
-                if (a + 5 > end) break;
-                const char sub = (char)a[0];
-                const uint32_t cnt = (uint32_t)le32(a + 1);
-                const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
-                len = 5 + es * (size_t)cnt;
-            } else break;                                   // unknown type: stop parsing
-            if (a + len > end) break;
-            a += len;
-        }
+        const char *sa; size_t sa_len;
+        if (bam_find_sa(p + need, p + bs, &sa, &sa_len)) { rec.sa.assign(sa, sa_len); rec.has_sa = true; }
     }
     r->inpos += 4 + (size_t)bs;
     return 0;
@@ -675,7 +685,9 @@ void ParsePipe::work_loop() {
 // bam_next_raw + bam_pump + the emit part of kdf_reader_next, on one chunk, without copying records
 void ParsePipe::parse(const RawChunk &in, ParsedChunk &o) const {
     o.off.clear(); o.flags.clear(); o.ref.clear(); o.pos.clear(); o.names.clear(); o.name_off.clear(); o.ordinal.clear();
+    o.cigar.clear(); o.cigar_off.clear(); o.sa.clear(); o.sa_off.clear(); o.qual.clear(); o.qual_off.clear(); o.mapq.clear();
     o.next = 0; o.err.clear();
+    const bool aux = r->want_aux;
     // every record carries >= (l_seq + 1) / 2 sequence bytes: positions <= 2 * bytes + records <= 2.1 * bytes
     const size_t max_pos = in.bytes.size() * 2 + in.bytes.size() / 16 + 64;
     o.packed.assign(max_pos / 32 + 4, 0); o.invalid.assign(max_pos / 64 + 4, 0);
@@ -692,6 +704,18 @@ void ParsePipe::parse(const RawChunk &in, ParsedChunk &o) const {
         o.name_off.push_back((int64_t)o.names.size());
         o.names.append((const char *)p + 32, l_rn ? l_rn - 1 : 0); o.names.push_back('\0');
         o.ordinal.push_back(x.ordinal);
+        if (aux) {
+            const uint8_t *cg = p + 32 + l_rn, *sq = cg + 4 * n_cig, *ql = sq + ((size_t)l_seq + 1) / 2;
+            o.cigar_off.push_back((int64_t)o.cigar.size());
+            for (unsigned i = 0; i < n_cig; ++i) o.cigar.push_back((uint32_t)le32(cg + 4 * i));
+            o.qual_off.push_back((int64_t)o.qual.size());
+            o.qual.insert(o.qual.end(), ql, ql + (size_t)l_seq);
+            o.mapq.push_back(p[9]);
+            const char *sa; size_t sa_len;
+            if (bam_find_sa(ql + (size_t)l_seq, p + x.bs, &sa, &sa_len)) {
+                o.sa_off.push_back((int64_t)o.sa.size()); o.sa.append(sa, sa_len); o.sa.push_back('\0');
+            } else o.sa_off.push_back(-1);
+        }
     };
     Ref best[3]; int score[3] = {-1, -1, -1};
     const uint8_t *run_name = nullptr; size_t run_len = 0; bool have_run = false;
@@ -727,6 +751,7 @@ void ParsePipe::parse(const RawChunk &in, ParsedChunk &o) const {
     }
     if (have_run) flush();
     o.off.push_back((int64_t)w.n);
+    if (aux) { o.cigar_off.push_back((int64_t)o.cigar.size()); o.qual_off.push_back((int64_t)o.qual.size()); }
 }
 
 ParsedChunk *ParsePipe::front(std::string &e) {
@@ -842,7 +867,7 @@ int kdf_reader_next(kdf_reader *r, uint64_t max_bases, int64_t max_reads, uint64
     if (r->kind == kdf_reader::BAM && !r->started) {
         r->started = true;
         // inflate takes ~60 % of the CPU time of a pass, parsing ~40 %: half as many parser threads
-        if (r->pool && !r->want_aux) r->pipe.reset(new ParsePipe(r, std::max(2, (r->threads + 1) / 2)));
+        if (r->pool) r->pipe.reset(new ParsePipe(r, std::max(2, (r->threads + 1) / 2)));
     }
     if (r->kind == kdf_reader::BAM && r->pipe) {
         // parallel parsing: append whole records of the parsed chunks, in file order
@@ -874,6 +899,18 @@ int kdf_reader_next(kdf_reader *r, uint64_t max_bases, int64_t max_reads, uint64
                 const int64_t shift = (int64_t)r->m_names.size() - nb0;
                 for (size_t t = i; t < j; ++t) r->m_name_off.push_back(c->name_off[t] + shift);
                 r->m_names.append(c->names, (size_t)nb0, (size_t)(nb1 - nb0));
+                if (r->want_aux) {
+                    const int64_t cs = (int64_t)r->m_cigar.size() - c->cigar_off[i], qs = (int64_t)r->m_qual.size() - c->qual_off[i];
+                    for (size_t t = i; t < j; ++t) { r->m_cigar_off.push_back(c->cigar_off[t] + cs); r->m_qual_off.push_back(c->qual_off[t] + qs); }
+                    r->m_cigar.insert(r->m_cigar.end(), c->cigar.begin() + c->cigar_off[i], c->cigar.begin() + c->cigar_off[j]);
+                    r->m_qual.insert(r->m_qual.end(), c->qual.begin() + c->qual_off[i], c->qual.begin() + c->qual_off[j]);
+                    r->m_mapq.insert(r->m_mapq.end(), c->mapq.begin() + (long)i, c->mapq.begin() + (long)j);
+                    for (size_t t = i; t < j; ++t) {
+                        if (c->sa_off[t] < 0) { r->m_sa_off.push_back(-1); continue; }
+                        r->m_sa_off.push_back((int64_t)r->m_sa.size());
+                        r->m_sa.append(c->sa.c_str() + c->sa_off[t]); r->m_sa.push_back('\0');
+                    }
+                }
                 n += (int64_t)(j - i);
                 c->next = j;
             }

@@ -79,7 +79,7 @@ def _collect_child_kmers(child_bam, ref_fasta, variants, kmer_size, min_baseq, m
     for v in variants:
         by_chrom[v["chrom"]].append(v)
     per_variant = {_variant_key(v): [] for v in variants}
-    rd = bam_reader(child_bam, flag_off=0, collapse=False, max_bases=1 << 24, want_aux=True)
+    rd = bam_reader(child_bam, flag_off=0, collapse=False, max_bases=1 << 24, threads=4, want_aux=True)
     refs = rd.references()
     with rd:
         for batch in rd:

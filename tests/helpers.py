@@ -28,7 +28,8 @@ def _bgzf_block(data: bytes) -> bytes:
 
 def write_bam(path, chroms, reads):
     """reads: dicts with name, seq and optional flag (0), ref (0; -1 unplaced),
-    pos (0-based), mapq (60), cigar ([(0, len)]), qual (True: has qualities).
+    pos (0-based), mapq (60), cigar ([(0, len)]), qual (True: has qualities),
+    aux (bytes: optional fields in BAM encoding, e.g. b"NMC\x01SAZchr1,5,+,10M,60,0;\0").
     Records are written in the given order (sort them yourself when needed)."""
     text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in chroms)
     out = bytearray(b"BAM\x01" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(chroms)))
@@ -46,7 +47,7 @@ def write_bam(path, chroms, reads):
         qual = (b"\x28" if r.get("qual", True) else b"\xff") * len(seq)
         body = struct.pack("<iiBBHHHiiii", r.get("ref", 0), r.get("pos", 0), len(name), r.get("mapq", 60), 4680,
                            len(cigar), r.get("flag", 0), len(seq), -1, -1, 0)
-        body += name + b"".join(struct.pack("<I", (ln << 4) | op) for op, ln in cigar) + bytes(sq) + qual
+        body += name + b"".join(struct.pack("<I", (ln << 4) | op) for op, ln in cigar) + bytes(sq) + qual + r.get("aux", b"")
         out += struct.pack("<i", len(body)) + body
     with open(path, "wb") as fh:
         data = bytes(out)

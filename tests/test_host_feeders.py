@@ -2,6 +2,7 @@
 `samtools fasta -F 0xD00` semantics and the FASTA reader, checked against the
 oracle's independent pure-Python readers on the reference's fixtures."""
 import os
+import struct
 
 import numpy as np
 import pytest
@@ -134,7 +135,11 @@ def _drain(path, **kw):
             assert inv[b - 1]                                            # the separator after every read
             seqs.append(bytes(chars[a:b - 1]))
             if st.flags is not None:
-                meta.append((int(st.flags[i]), int(st.ref_ids[i]), int(st.positions[i]), st.name(i), int(st.ordinals[i])))
+                m = (int(st.flags[i]), int(st.ref_ids[i]), int(st.positions[i]), st.name(i), int(st.ordinals[i]))
+                if st.cigar is not None:
+                    q = st.qualities(i)
+                    m += (tuple(st.cigartuples(i)), st.sa_tag(i), None if q is None else bytes(q), int(st.mapq[i]))
+                meta.append(m)
     return seqs, meta
 
 
@@ -151,6 +156,11 @@ def test_parallel_parsing_equals_sequential(collapse, flag_off):
         got = _drain(path, flag_off=flag_off, collapse=collapse, threads=4, want_meta=True, **kw)
         assert got[0] == ref[0], kw
         assert got[1] == ref[1], kw
+    # alignment details (CIGAR, SA, qualities, MAPQ) through the parallel parser
+    ref_aux = _drain(path, flag_off=flag_off, collapse=collapse, threads=1, want_aux=True, max_bases=1 << 22)
+    assert all(len(m) == 9 for m in ref_aux[1]) and any(m[5] for m in ref_aux[1])
+    for kw in (dict(max_bases=1 << 22), dict(max_bases=9_001, max_reads=17)):
+        assert _drain(path, flag_off=flag_off, collapse=collapse, threads=4, want_aux=True, **kw) == ref_aux, kw
     # no metadata wanted; early close in mid-stream must not hang
     from kmer_denovo_filter_amd import bam_reader
     assert _drain(path, flag_off=flag_off, collapse=collapse, threads=3, max_bases=1 << 20)[0] == ref[0]
@@ -168,10 +178,19 @@ def test_parallel_parsing_synthetic_runs(tmp_path):
         name = f"q{i // 3}"                                               # runs of 3 records
         flag = [0x41, 0x81, 0x941][i % 3] if i % 7 else 0x141               # supplementary third record; some secondary R1s
         seq = B[rng.integers(0, 5, int(rng.integers(1, 90)), dtype=np.int64).clip(0, 4)].tobytes().decode()
-        reads.append({"name": name, "seq": seq, "pos": i, "flag": flag})
+        aux = b""
+        if i % 5 == 0:       # optional fields of several types in front of SA:Z (the walker must step over them)
+            aux = (b"NMC\x03" + b"ASi" + struct.pack("<i", -7) + b"XBBs" + struct.pack("<i", 2) + struct.pack("<hh", 1, 2)
+                   + b"MDZ10A5\0" + b"SAZ" + f"chr1,{i + 1},+,20M30S,60,1;".encode() + b"\0" + b"XSf" + struct.pack("<f", 1.5))
+        reads.append({"name": name, "seq": seq, "pos": i, "flag": flag, "aux": aux, "qual": bool(i % 4)})
     path = str(tmp_path / "runs.bam")
     write_bam(path, [("chr1", 1_000_000)], reads)
     for collapse, flag_off in ((True, 0xD00), (True, 0x900), (False, 0x100)):
         ref = _drain(path, flag_off=flag_off, collapse=collapse, threads=1, want_meta=True)
         for kw in (dict(), dict(max_bases=4096, max_reads=50)):
             assert _drain(path, flag_off=flag_off, collapse=collapse, threads=5, want_meta=True, **kw) == ref
+        ref_aux = _drain(path, flag_off=flag_off, collapse=collapse, threads=1, want_aux=True)
+        sa = [m[6] for m in ref_aux[1] if m[6]]
+        assert sa and all(x.startswith("chr1,") and x.endswith(",20M30S,60,1;") for x in sa)
+        assert any(m[7] is None for m in ref_aux[1]) and any(m[7] is not None for m in ref_aux[1])
+        assert _drain(path, flag_off=flag_off, collapse=collapse, threads=5, want_aux=True, max_bases=5000, max_reads=64) == ref_aux
