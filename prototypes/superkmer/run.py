@@ -150,7 +150,7 @@ def main():
     with KmerEngine(31, capacity_hint=1 << 20) as e:
         e.count_dev(ds.packed.data_ptr(), ds.invalid.data_ptr(), ds.n_bases); e.synchronize()
         _, distinct, windows = e.stats(); ge3 = e.count_ge(3)
-    stage2(rec[:n], bkt[:n], tot[1], distinct, ge3, nb_bits=8)
+    stage2(rec[:n], bkt[:n], tot[1], distinct, ge3, nb_bits=8, versions=(1, 2, 3))
     # 2. the bench workload
     reads_n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
     ds = synth_stream(reads_n, 150, 100_000_000, seed=20260417, device=dev); torch.cuda.synchronize()
@@ -163,9 +163,8 @@ def main():
           f"count kernel {ms[0]:.2f} ms, emit kernel {ms[1]:.2f} ms; record bytes {tot[0] * 16 / 1e9:.2f} GB vs k-mer bytes {tot[1] * 8 / 1e9:.2f} GB", flush=True)
     assert tot[1] == windows
     n = tot[2]
-    stage2(rec[:n], bkt[:n], tot[1], distinct, ge3)
-    stage2(rec[:n], bkt[:n], tot[1], distinct, ge3, nb_bits=18)
-    stage2(rec[:n], bkt[:n], tot[1], distinct, ge3, nb_bits=17, versions=(1,), balanced=True)
+    stage2(rec[:n], bkt[:n], tot[1], distinct, ge3, nb_bits=18, versions=(1, 3))
+    stage2(rec[:n], bkt[:n], tot[1], distinct, ge3, nb_bits=17, versions=(1, 3), balanced=True)
     stage2(rec[:n], bkt[:n], tot[1], distinct, ge3, nb_bits=18, versions=(1,), balanced=True)
     # distinct records / k-mer inserts after dedupe (what stage 2 would insert)
     r = rec[:n]

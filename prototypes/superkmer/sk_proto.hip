@@ -406,6 +406,131 @@ __global__ __launch_bounds__(SKB_THREADS) void sk_bucket2_kernel(const SkRecord 
     }
 }
 
+// Stage 2, third version: like v1 (representatives stay in global memory) but the expansion runs over a FLAT
+// list of (distinct record, k-mer index) items, so every lane has work whatever the record lengths are, and
+// the insert reads two slots of the probe sequence up front (kernel C's scheme; the tail is probed in a loop).
+__global__ __launch_bounds__(SKB_THREADS) void sk_bucket3_kernel(const SkRecord *__restrict__ recs, const uint32_t *__restrict__ boff,
+                                                                uint64_t *__restrict__ tab_lo, uint32_t *__restrict__ tab_cnt,
+                                                                unsigned long long *stats)
+{
+    constexpr uint32_t B = 1u << SKB_BB, bmask = B - 1, NONE = 0xFFFFFFFFu;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t *tlo = (uint64_t *)smem;                  // [B]
+    uint32_t *tcnt = (uint32_t *)(tlo + B);            // [B]
+    uint32_t *own = tcnt + B, *mult = own + SKB_RT;    // [RT] representative record / multiplicity per dedupe slot
+    uint32_t *lq = mult + SKB_RT;                      // [RT + 1] list: dedupe slot of entry e
+    uint32_t *lp = lq + SKB_RT + 4;                    // [RT + 4] list: first flat item of entry e (padded with the total)
+    __shared__ uint32_t wsum[20];
+    __shared__ uint32_t sh_claimed, sh_over, sh_exp, sh_ge3, sh_ne, sh_items;
+    __shared__ unsigned long long sh_sum;
+    const uint32_t bucket = blockIdx.x;
+    const uint32_t r0 = boff[bucket], r1 = boff[bucket + 1], nrec = r1 - r0;
+    for (uint32_t i = threadIdx.x; i < B; i += SKB_THREADS) { tlo[i] = KDF_EMPTY; tcnt[i] = 0; }
+    for (uint32_t i = threadIdx.x; i < SKB_RT; i += SKB_THREADS) { own[i] = NONE; mult[i] = 0; }
+    if (threadIdx.x == 0) { sh_claimed = 0; sh_over = 0; sh_exp = 0; sh_ge3 = 0; sh_sum = 0; }
+    __syncthreads();
+    // ---- dedupe (as v1)
+    uint32_t over = 0;
+    for (uint32_t r = threadIdx.x; r < nrec; r += SKB_THREADS) {
+        const SkRecord me = recs[r0 + r];
+        uint32_t sl = (uint32_t)(kdf_mix64(me.lo ^ (me.hi * 0xC2B2AE3D27D4EB4Full)) >> 40) & (SKB_RT - 1);
+        bool done = false;
+        for (uint32_t n = 0; n < SKB_RT && !done; ++n) {
+            uint32_t o = own[sl];
+            if (o == NONE) {
+                o = atomicCAS(&own[sl], NONE, r);
+                if (o == NONE) { atomicAdd(&mult[sl], 1u); done = true; break; }
+            }
+            const SkRecord rep = recs[r0 + o];
+            if (rep.lo == me.lo && rep.hi == me.hi) { atomicAdd(&mult[sl], 1u); done = true; break; }
+            sl = (sl + 1) & (SKB_RT - 1);
+        }
+        if (!done) ++over;
+    }
+    if (over) atomicAdd(&sh_over, over);
+    __syncthreads();
+    // ---- list of distinct records with the prefix of their k-mer counts: thread t owns dedupe slots [t*PER, +PER)
+    constexpr uint32_t PER = SKB_RT / SKB_THREADS;
+    uint32_t nk_[PER], cnt = 0, items = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) {
+        const uint32_t o = own[threadIdx.x * PER + u];
+        nk_[u] = o == NONE ? 0u : (uint32_t)(recs[r0 + o].hi >> 58);
+        cnt += nk_[u] ? 1u : 0u; items += nk_[u];
+    }
+    {
+        uint32_t v = (cnt << 16) | items, inc = v;                        // both sums stay below 65536
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t acc = 0;
+            for (int i = 0; i < SKB_THREADS / 64; ++i) { const uint32_t t = wsum[i]; wsum[i] = acc; acc += t; }
+            sh_ne = acc >> 16; sh_items = acc & 0xFFFFu;
+        }
+        __syncthreads();
+        uint32_t ex = wsum[wave] + inc - v;
+        uint32_t e = ex >> 16, pf = ex & 0xFFFFu;
+#pragma unroll
+        for (uint32_t u = 0; u < PER; ++u) if (nk_[u]) { lq[e] = threadIdx.x * PER + u; lp[e] = pf; ++e; pf += nk_[u]; }
+    }
+    __syncthreads();
+    const uint32_t ne = sh_ne, total = sh_items;
+    if (threadIdx.x < 4) lp[ne + threadIdx.x] = total;                    // padding for the windowed search
+    __syncthreads();
+    // ---- flat expansion
+    uint32_t claimed = 0, expn = 0;
+    const unsigned long long inv_total = total ? (((unsigned long long)ne << 32) / total) : 0;
+    for (uint32_t i = threadIdx.x; i < total; i += SKB_THREADS) {
+        uint32_t e = (uint32_t)(((unsigned long long)i * inv_total) >> 32);
+        if (e >= ne) e = ne - 1;
+        while (lp[e] > i) --e;
+        while (lp[e + 1] <= i) ++e;
+        const uint32_t slot = lq[e], j = i - lp[e];
+        const SkRecord rec = recs[r0 + own[slot]];
+        const uint32_t c = mult[slot];
+        const uint64_t hi = rec.hi & ((1ull << 58) - 1);
+        const uint64_t key = kdf_canon_narrow(kdf_funnel(rec.lo, hi, 2 * (int)j), SK_K, (1ull << (2 * SK_K)) - 1);
+        uint32_t sl = (uint32_t)(kdf_mix64(key) >> 20) & bmask;
+        // two slots up front, resolved in straight-line code; the rest in a loop
+        const uint64_t c0 = tlo[sl], c1 = tlo[(sl + 1) & bmask];
+        bool done = false;
+        if (c0 == key) { atomicAdd(&tcnt[sl], c); done = true; }
+        else if (c0 != KDF_EMPTY && c1 == key) { atomicAdd(&tcnt[(sl + 1) & bmask], c); done = true; }
+        if (!done) {
+            for (uint32_t n = 0; n <= bmask; ++n) {
+                uint64_t cur = tlo[sl];
+                if (cur == KDF_EMPTY) {
+                    cur = atomicCAS((unsigned long long *)&tlo[sl], KDF_EMPTY, key);
+                    if (cur == KDF_EMPTY) { ++claimed; cur = key; }
+                }
+                if (cur == key) { atomicAdd(&tcnt[sl], c); break; }
+                sl = (sl + 1) & bmask;
+            }
+        }
+        ++expn;
+    }
+    if (claimed) atomicAdd(&sh_claimed, claimed);
+    if (expn) atomicAdd(&sh_exp, expn);
+    __syncthreads();
+    uint32_t ge3 = 0; unsigned long long sum = 0;
+    const uint64_t slot0 = (uint64_t)bucket << SKB_BB;
+    for (uint32_t i = threadIdx.x; i < B; i += SKB_THREADS) {
+        const uint32_t c = tcnt[i];
+        tab_lo[slot0 + i] = tlo[i]; tab_cnt[slot0 + i] = c;
+        ge3 += c >= 3; sum += c;
+    }
+    for (int o = 32; o > 0; o >>= 1) { ge3 += __shfl_xor(ge3, o); sum += __shfl_xor(sum, o); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&sh_sum, sum); atomicAdd(&sh_ge3, ge3); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long *row = stats + (size_t)bucket * 8;
+        row[0] = sh_claimed; row[1] = sh_sum; row[2] = sh_ge3; row[3] = sh_over; row[4] = sh_exp; row[5] = ne; row[6] = nrec; row[7] = 0;
+    }
+}
+
 extern "C" {
 
 // returns 0 or a HIP error code; ms[0] = count kernel, ms[1] = emit kernel (HIP events); totals[0..2] = records, windows, emitted
@@ -450,14 +575,19 @@ int sk_buckets(const void *d_recs, const void *d_boff, uint32_t n_buckets, void 
     unsigned long long *d_st = (unsigned long long *)stats_out;      // DEVICE array [n_buckets][8]
     hipError_t e;
     const size_t lds = version == 2 ? (size_t)(1u << SKB_BB) * 12 + (size_t)SKB_QCAP * 20 + 1024 * 4
+                     : version == 3 ? (size_t)(1u << SKB_BB) * 12 + (size_t)SKB_RT * 16 + 64
                                     : (size_t)(1u << SKB_BB) * 12 + (size_t)SKB_RT * 12;
     if ((e = hipFuncSetAttribute((const void *)sk_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return (int)e;
     if ((e = hipFuncSetAttribute((const void *)sk_bucket2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return (int)e;
+    if ((e = hipFuncSetAttribute((const void *)sk_bucket3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return (int)e;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     float best = 1e30f;
     for (int r = 0; r < reps; ++r) {
         (void)hipEventRecord(e0, 0);
-        if (version == 2)
+        if (version == 3)
+            hipLaunchKernelGGL(sk_bucket3_kernel, dim3(n_buckets), dim3(SKB_THREADS), lds, 0, (const SkRecord *)d_recs, (const uint32_t *)d_boff,
+                               (uint64_t *)d_tab_lo, (uint32_t *)d_tab_cnt, d_st);
+        else if (version == 2)
             hipLaunchKernelGGL(sk_bucket2_kernel, dim3(n_buckets), dim3(SKB_THREADS), lds, 0, (const SkRecord *)d_recs, (const uint32_t *)d_boff,
                                (uint64_t *)d_tab_lo, (uint32_t *)d_tab_cnt, d_st);
         else
