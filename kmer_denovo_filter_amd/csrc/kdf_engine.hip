@@ -555,12 +555,11 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     if (n_entries == 0) { if (h->prof) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); for (hipEvent_t e : sev) (void)hipEventDestroy(e); } return KDF_OK; }
 
     const uint64_t nb_table = 1ull << (plan.c1 + plan.c2 + plan.sub_bits);
-    if ((rc = kb_reserve(h, 0, n_entries * 8))) return rc;
-    if (KW == 2 && (rc = kb_reserve(h, 1, n_entries * 8))) return rc;
+    if ((rc = kb_reserve(h, 0, n_entries * 8 * KW))) return rc;             // wide: 16-byte (lo, hi) entries
     if ((rc = kb_reserve(h, 2, n_chunks * (size_t)plan.off_stride * 4))) return rc;
     const size_t failed_bytes = (size_t)((nb_table + 31) / 32) * 4;
     if ((rc = kb_reserve(h, 3, failed_bytes))) return rc;
-    s.ent_lo = (uint64_t *)h->kb_buf[0]; s.ent_hi = (uint64_t *)h->kb_buf[1];
+    s.ent_lo = (uint64_t *)h->kb_buf[0];
     s.chunk_off = (uint32_t *)h->kb_buf[2]; s.failed = (uint32_t *)h->kb_buf[3];
     HIPCHK(h, hipMemsetAsync(s.failed, 0, failed_bytes, h->stream));
 
