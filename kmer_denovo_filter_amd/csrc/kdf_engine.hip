@@ -524,7 +524,8 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     s.chunk_first = s.bin_start + 2 * (nb1 + 1); s.totals = s.chunk_first + (nb1 + 1);
     s.failed_flag = (unsigned int *)(s.totals + 8);
     const size_t lds_b = (size_t)CHUNK * 8 * KW + (size_t)(2 * KB_F + 32) * 4 + 16;
-    const size_t lds_c = ((size_t)8 * KW + 4) * ((size_t)1 << plan.bucket_bits) + (2 + 32 + KB_C_RUNS) * 4 + (size_t)KB_C_RUNS * 8;
+    const size_t lds_c = ((size_t)8 * KW + 4) * ((size_t)1 << plan.bucket_bits) + (2 + 32 + KB_C_RUNS) * 4 + (size_t)KB_C_RUNS * 8
+                         + (KW == 2 ? (size_t)KB_C_RUNS * 4 : 0);                           // wide: run_hi
     const size_t lds_a1 = (size_t)(SLAB + 2) * 8 * KW + (size_t)nb1 * 16 + (size_t)(2 * (nb1 + 32) + 32) * 4;
     int rc = kb_set_lds_attrs<KW>(h, lds_a1, lds_b, lds_c);
     if (rc) return rc;
