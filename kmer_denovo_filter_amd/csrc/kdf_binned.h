@@ -468,15 +468,55 @@ __device__ __forceinline__ void kb_probe_narrow(uint64_t *tlo, uint32_t *tcnt, u
     }
 }
 
+// wide keys, one ATTEMPT from slot `sl`: 0 done, 1 bucket full, 2 blocked by a slot another lane is publishing.
+// The caller retries blocked keys under a wave-uniform loop: no lane ever waits inside a divergent loop.
+template <int MODE>
+__device__ __forceinline__ int kb_probe_wide_once(uint64_t *tlo, uint64_t *thi, uint32_t *tcnt, uint32_t bmask,
+                                                  uint64_t klo, uint64_t khi, uint32_t sl, uint32_t &claimed) {
+    for (uint32_t n = 0; n <= bmask; ++n) {
+        uint64_t chi = __hip_atomic_load(&thi[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (chi == KDF_EMPTY && MODE == KB_MODE_INSERT) {
+            chi = atomicCAS((unsigned long long *)&thi[sl], KDF_EMPTY, khi | KDF_PENDING);
+            if (chi == KDF_EMPTY) {
+                __hip_atomic_store(&tlo[sl], klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&thi[sl], khi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                claimed++;
+                atomicAdd(&tcnt[sl], 1u);
+                return 0;
+            }
+        }
+        if (chi == KDF_EMPTY) return 0;                           // FILTERED: absent
+        if ((chi & ~KDF_PENDING) == khi) {
+            if (chi & KDF_PENDING) return 2;
+            const uint64_t clo = __hip_atomic_load(&tlo[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (clo == klo) { atomicAdd(&tcnt[sl], 1u); return 0; }
+        }
+        sl = (sl + 1) & bmask;
+    }
+    return 1;
+}
+// all lanes of the wave call this together (`todo`: this lane has a key); returns when every key is placed
+template <int MODE>
+__device__ __forceinline__ void kb_probe_wide_wave(uint64_t *tlo, uint64_t *thi, uint32_t *tcnt, uint32_t bmask, bool todo,
+                                                   uint64_t klo, uint64_t khi, uint32_t sl, uint32_t &claimed, bool &failed) {
+    while (__any(todo)) {
+        if (todo) {
+            const int res = kb_probe_wide_once<MODE>(tlo, thi, tcnt, bmask, klo, khi, sl, claimed);
+            if (res != 2) { todo = false; if (res == 1) failed = true; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // VAR 0: every lane probes its key in a loop (a wave pays the longest probe of its
-// 64 lanes for every key).  VAR 1 (narrow keys, INSERT / FILTERED): the first
-// KB_C_LA slots of the probe sequence are read at once and resolved in straight-line
-// code; the keys that need more go to a wave-private queue in LDS (ballot + mbcnt,
-// no atomics, no barrier) and are probed densely, one per lane, after the batch.
-// Measured on the bench pass: kernel C 7.6 -> 6.5 ms.
+// 64 lanes for every key).  VAR 1 (INSERT / FILTERED): the first KB_C_LA slots of
+// the probe sequence are read at once and resolved in straight-line code; the keys
+// that need more go to a wave-private queue in LDS (ballot + mbcnt, no atomics, no
+// barrier) and are probed densely, one per lane, after the batch.  Measured on the
+// bench pass: kernel C 7.6 -> 6.5 ms at k = 31, 16.0 -> 12.7 ms at k = 63.
 #define KB_C_LA    2                   // VAR 1: slots of the probe sequence read up front
 #define KB_C_QCAP  1024                // VAR 1: queue entries per workgroup (KB_C_QCAP / 8 per wave)
-#define KB_C_QEXTRA(VAR) ((VAR) ? (KB_C_QCAP * 10 + 16 + (KB_C_RUNS + 4) * 4) : 0)   // LDS bytes VAR 1 adds
+#define KB_C_QEXTRA(VAR, KW) ((VAR) ? (KB_C_QCAP * ((KW) == 2 ? 18 : 10) + 16 + (KB_C_RUNS + 4) * 4) : 0)   // LDS bytes VAR 1 adds
 template <int KW, int MODE, int VAR>
 __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
     KbPlan plan, KbScratch s, KdfTable t, KdfCtl *ctl, int table_nonempty)
@@ -491,8 +531,10 @@ __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
     uint32_t *wsum = tcnt + B + 2;                            // [32]
     uint32_t *run_pref = wsum + 32;                           // [KB_C_RUNS] exclusive prefix of run lengths
     unsigned long long *run_first = (unsigned long long *)(run_pref + KB_C_RUNS);   // [KB_C_RUNS] (B + 34 + KB_C_RUNS is even: 8-aligned)
-    uint64_t *qk = (uint64_t *)(run_first + KB_C_RUNS);       // [KB_C_QCAP] VAR 1: keys whose probe goes past the lookahead (per wave: KB_C_QCAP / 8)
+    uint32_t *run_hi = (uint32_t *)(run_first + KB_C_RUNS);   // [KB_C_RUNS] wide keys only: distance (words) from a run's lo words to its hi words
+    uint64_t *qk = (uint64_t *)(run_hi + (KW == 2 ? KB_C_RUNS : 0));   // [KB_C_QCAP] VAR 1: keys whose probe goes past the lookahead (per wave: KB_C_QCAP / 8)
     uint16_t *qs = (uint16_t *)(qk + KB_C_QCAP);              // [KB_C_QCAP] slot to go on from
+    uint64_t *qk2 = (uint64_t *)((uint32_t *)(qs + KB_C_QCAP) + 2 + KB_C_RUNS + 4);   // [KB_C_QCAP] wide keys: hi words of the queued keys
     uint32_t *rpw = (uint32_t *)(qs + KB_C_QCAP) + 2;                                  // [KB_C_RUNS + 4] VAR >= 1: run_pref shifted by one, padded with `total`
 
     // `plan` describes the table the partition was built for.  In MODE_REPLAY
@@ -525,11 +567,11 @@ __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
 
     constexpr uint32_t WQ = KB_C_QCAP / (KB_C_THREADS / 64);
     uint64_t *wqk = qk + (threadIdx.x >> 6) * WQ;
+    uint64_t *wqk2 = qk2 + (threadIdx.x >> 6) * WQ;
     uint16_t *wqs = qs + (threadIdx.x >> 6) * WQ;
     uint32_t wq_n = 0;
     const unsigned long long j0 = s.chunk_first[c], j1 = s.chunk_first[c + 1];
     const unsigned long long bstart = s.bin_start[c], bend = s.bin_start[c + 1];
-    uint32_t *run_hi = (uint32_t *)(run_first + KB_C_RUNS);   // [KB_C_RUNS] wide keys: distance (words) from a run's lo words to its hi words
     const uint32_t bmask = B - 1;
     uint32_t claimed = 0;
     bool failed = false;
@@ -561,12 +603,12 @@ __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
         }
         __syncthreads();
         const uint32_t nruns = (uint32_t)((j1 - jb) < (unsigned long long)KB_C_RUNS ? (j1 - jb) : (unsigned long long)KB_C_RUNS);
-        constexpr int EPB = VAR >= 1 ? 20 : 16;    // entries per thread per batch: EPB loads in flight per lane
+        constexpr int EPB = VAR >= 1 ? (KW == 2 ? 12 : 20) : 16;    // entries per thread per batch: EPB (x KW) loads in flight per lane
         // (ei * inv_total) >> 32 ~= ei * nruns / total
         const unsigned long long inv_total = total ? (((unsigned long long)nruns << 32) / total) : 0;
         for (uint32_t e0 = 0; e0 < total; e0 += KB_C_THREADS * EPB) {   // wave-uniform trip count
           uint64_t bklo[EPB], bkhi[KW == 2 ? EPB : 1];
-          if constexpr (VAR >= 1 && KW == 1) {
+          if constexpr (VAR >= 1) {
             // windowed search: the guess is within a run or two of the answer, so read
             // run_pref[guess-1 .. guess+2] for four entries at once and count -- two LDS
             // round trips per four entries instead of a dependent probe chain per entry
@@ -574,7 +616,7 @@ __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
             for (int q0 = 0; q0 < EPB; q0 += 4) {
                 if (e0 + q0 * KB_C_THREADS >= total) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) bklo[q0 + g] = 0;
+                    for (int g = 0; g < 4; ++g) { bklo[q0 + g] = 0; if constexpr (KW == 2) bkhi[q0 + g] = 0; }
                     continue;
                 }
                 uint32_t w[4][4], gs[4];
@@ -613,8 +655,12 @@ __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const uint32_t ei = e0 + (q0 + g) * KB_C_THREADS + threadIdx.x;
-                    bklo[q0 + g] = 0;
-                    if (ei < total) bklo[q0 + g] = s.ent_lo[rf[g] + (ei - pf4[g])];
+                    bklo[q0 + g] = 0; if constexpr (KW == 2) bkhi[q0 + g] = 0;
+                    if (ei < total) {
+                        const unsigned long long src = rf[g] + (ei - pf4[g]);
+                        bklo[q0 + g] = s.ent_lo[src];
+                        if constexpr (KW == 2) bkhi[q0 + g] = s.ent_lo[src + run_hi[lo4[g]]];
+                    }
                 }
             }
           } else {
@@ -702,6 +748,88 @@ __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
                     kb_probe_narrow<MODE>(tlo, tcnt, bmask, wqk[i], wqs[i], claimed, failed);
                 wq_n = 0;
             }
+          } else if constexpr (VAR >= 1 && KW == 2 && MODE != KB_MODE_REPLAY) {
+            // Two-word keys, same scheme.  The hi words of the lookahead slots are read BEFORE their lo
+            // words (LDS serves a wave's instructions in order and a claimer writes lo before the final
+            // hi), so a slot whose hi reads as the key's hi without PENDING has its lo in place.  A slot
+            // seen PENDING with this hi may become this key: it goes to the queue.  The straight-line
+            // code never waits; the queue is drained under the wave-uniform retry loop.
+            constexpr int G = 2;
+#pragma unroll
+            for (int q0 = 0; q0 < EPB; q0 += G) {
+                if (e0 + q0 * KB_C_THREADS >= total) break;
+                uint64_t chi[G][KB_C_LA], clo[G][KB_C_LA]; uint32_t sl0[G]; bool td[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const uint32_t ei = e0 + (q0 + g) * KB_C_THREADS + threadIdx.x;
+                    const uint64_t home = kdf_hash(bklo[q0 + g], bkhi[q0 + g]) >> (64 - plan.log2cap);
+                    td[g] = ei < total && !(plan.sub_bits && (home >> plan.bucket_bits) != bucket);
+                    sl0[g] = (uint32_t)home & bmask;
+#pragma unroll
+                    for (int i = 0; i < KB_C_LA; ++i) chi[g][i] = __hip_atomic_load(&thi[(sl0[g] + i) & bmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int i = 0; i < KB_C_LA; ++i) asm volatile("" : "+v"(chi[g][i]) :: "memory");      // hi words first ...
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int i = 0; i < KB_C_LA; ++i) clo[g][i] = __hip_atomic_load(&tlo[(sl0[g] + i) & bmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int i = 0; i < KB_C_LA; ++i) asm volatile("" : "+v"(clo[g][i]) :: "memory");      // ... then the lo words
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const uint64_t klo = bklo[q0 + g], khi = bkhi[q0 + g];
+                    uint32_t r = KB_C_LA; int kind = 0;                      // 1 the key, 2 empty, 3 this hi, still PENDING
+#pragma unroll
+                    for (int i = KB_C_LA - 1; i >= 0; --i) {
+                        const uint64_t h = chi[g][i];
+                        const bool same = (h & ~KDF_PENDING) == khi;
+                        const bool m = h == khi && clo[g][i] == klo, e = h == KDF_EMPTY, pd = same && (h & KDF_PENDING);
+                        if (m || e || pd) { r = (uint32_t)i; kind = m ? 1 : (e ? 2 : 3); }
+                    }
+                    if (!__any(td[g])) continue;
+                    uint32_t sl = (sl0[g] + r) & bmask;
+                    bool hit = td[g] && kind == 1;
+                    bool more = td[g] && (r == KB_C_LA || kind == 3);
+                    if (td[g] && kind == 2) {
+                        if constexpr (MODE == KB_MODE_INSERT) {
+                            const uint64_t old = atomicCAS((unsigned long long *)&thi[sl], KDF_EMPTY, khi | KDF_PENDING);
+                            if (old == KDF_EMPTY) {
+                                __hip_atomic_store(&tlo[sl], klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_store(&thi[sl], khi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                claimed++; hit = true;
+                            } else {
+                                more = true;                                 // taken meanwhile: by this key (same hi) or by another
+                                if ((old & ~KDF_PENDING) != khi) sl = (sl + 1) & bmask;
+                            }
+                        }                                                    // FILTERED: absent
+                    }
+                    if (hit) atomicAdd(&tcnt[sl], 1u);
+                    const unsigned long long mk = __ballot(more);
+                    if (mk) {
+                        const uint32_t at = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                        const bool queued = more && at < WQ;
+                        if (queued) { wqk[at] = klo; wqk2[at] = khi; wqs[at] = (uint16_t)sl; }
+                        wq_n += (uint32_t)__popcll(mk);
+                        // queue full: place the key now, under the wave-uniform retry loop
+                        kb_probe_wide_wave<MODE>(tlo, thi, tcnt, bmask, more && !queued, klo, khi, sl, claimed, failed);
+                    }
+                }
+            }
+            {
+                const uint32_t nq = wq_n < WQ ? wq_n : WQ;
+                for (uint32_t b0 = 0; b0 < nq; b0 += 64) {                  // wave-uniform trip count
+                    const uint32_t i = b0 + (threadIdx.x & 63);
+                    const bool todo = i < nq;
+                    const uint64_t klo = todo ? wqk[i] : 0, khi = todo ? wqk2[i] : 0;
+                    kb_probe_wide_wave<MODE>(tlo, thi, tcnt, bmask, todo, klo, khi, todo ? (uint32_t)wqs[i] : 0u, claimed, failed);
+                }
+                wq_n = 0;
+            }
           } else {
 #pragma unroll
           for (int q = 0; q < EPB; ++q) {
@@ -726,36 +854,8 @@ __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
             } else {
                 // wide: claim hi with PENDING, publish lo, then the final hi (all in LDS).
                 // No lane waits inside a divergent loop (kdf_device.h): a lane that meets
-                // a PENDING slot retries in the next pass of this wave-uniform loop.
-                while (__any(todo)) {
-                    if (todo) {
-                        uint32_t sl = (uint32_t)home & bmask;
-                        int res = -1;                                    // -1 probing, 0 done, 1 full, 2 blocked
-                        for (uint32_t n = 0; res < 0; ++n) {
-                            if (n > bmask) { res = 1; break; }
-                            uint64_t chi = __hip_atomic_load(&thi[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (chi == KDF_EMPTY && MODE == KB_MODE_INSERT) {
-                                chi = atomicCAS((unsigned long long *)&thi[sl], KDF_EMPTY, khi | KDF_PENDING);
-                                if (chi == KDF_EMPTY) {
-                                    __hip_atomic_store(&tlo[sl], klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    __hip_atomic_store(&thi[sl], khi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    claimed++;
-                                    atomicAdd(&tcnt[sl], 1u);
-                                    res = 0; break;
-                                }
-                            }
-                            if (chi == KDF_EMPTY) { res = 0; break; }    // FILTERED: absent
-                            if ((chi & ~KDF_PENDING) == khi) {
-                                if (chi & KDF_PENDING) { res = 2; break; }
-                                const uint64_t clo = __hip_atomic_load(&tlo[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                if (clo == klo) { atomicAdd(&tcnt[sl], 1u); res = 0; break; }
-                            }
-                            sl = (sl + 1) & bmask;
-                        }
-                        if (res != 2) { todo = false; if (res == 1) failed = true; }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
+                // a PENDING slot retries in the next pass of a wave-uniform loop.
+                kb_probe_wide_wave<MODE>(tlo, thi, tcnt, bmask, todo, klo, khi, (uint32_t)home & bmask, claimed, failed);
             }
           }
         }

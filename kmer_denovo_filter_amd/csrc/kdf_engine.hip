@@ -478,9 +478,9 @@ static int kb_set_lds_attrs(kdf_engine *h, size_t a1, size_t b, size_t c) {
     HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_FILTERED, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c));
     HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_REPLAY, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c));
 #define KB_SETV(V) \
-    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_INSERT, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(c + KB_C_QEXTRA(V)))); \
-    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_FILTERED, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(c + KB_C_QEXTRA(V))));
-    if constexpr (KW == 1) { KB_SETV(1) }
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_INSERT, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(c + KB_C_QEXTRA(V, KW)))); \
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_FILTERED, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(c + KB_C_QEXTRA(V, KW))));
+    KB_SETV(1)
 #undef KB_SETV
     return KDF_OK;
 }
@@ -570,11 +570,11 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     stamp();                                                   // end of B
     if (filtered && (rc = materialize(h))) return rc;
     // narrow keys: lookahead + wave-queue variant of kernel C (debug flag 8 selects the plain loop, for A/B runs)
-    const bool var1 = KW == 1 && !(h->opt_debug_flags & 8);
+    const bool var1 = !(h->opt_debug_flags & 8);
     const int nonempty = h->lazy_empty ? 0 : 1;   // 0: kernel C rewrites every bucket (this IS the clear)
     if (filtered)
-#define KB_LV(M, V) hipLaunchKernelGGL((kb_bucket_kernel<KW, M, V>), dim3((unsigned)nb_table), dim3(KB_C_THREADS), lds_c + KB_C_QEXTRA(V), h->stream, plan, s, h->t, h->ctl, nonempty)
-#define KB_LVS(M) do { if constexpr (KW == 1) KB_LV(M, 1); } while (0)
+#define KB_LV(M, V) hipLaunchKernelGGL((kb_bucket_kernel<KW, M, V>), dim3((unsigned)nb_table), dim3(KB_C_THREADS), lds_c + KB_C_QEXTRA(V, KW), h->stream, plan, s, h->t, h->ctl, nonempty)
+#define KB_LVS(M) KB_LV(M, 1)
         if (var1) KB_LVS(KB_MODE_FILTERED);
         else hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_FILTERED, 0>), dim3((unsigned)nb_table), dim3(KB_C_THREADS), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty);
     else
