@@ -80,7 +80,11 @@ int kdf_stats(kdf_engine *h, uint64_t *capacity, uint64_t *distinct, uint64_t *w
 /* Tuning knobs and counters (tests force either kernel path through these):
  *   options  "force_path" 0 auto / 1 direct global-table kernels / 2 binned
  *            LDS-bucket pipeline; "binned_min_positions" (stream positions from
- *            which count calls take the binned path); "binned_max_positions" (positions per
+ *            which count calls take the binned path); "key_parts" / "key_part" (count only
+ *            the windows whose key lies in slice key_part of key_parts of the key space --
+ *            ranges of the LOW 16 hash bits, so a slice spreads over the whole table -- so that
+ *            a sample whose distinct k-mers exceed one table is counted slice by slice over
+ *            the same stream; insert mode only; 0/1 = everything); "binned_max_positions" (positions per
  *            binned pass, <= 2^31: longer streams take several passes); "binned_filtered_min_log2cap"
  *   stats    "binned_passes", "replayed_buckets", "log2cap", "bucket_bits" */
 int kdf_set_option(kdf_engine *h, const char *name, int64_t value);

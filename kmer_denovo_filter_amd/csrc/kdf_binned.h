@@ -44,6 +44,7 @@ struct KbPlan {
     uint32_t sub_bits;      // table buckets per partition bucket = 2^sub_bits
     uint32_t log2cap, bucket_bits;
     uint32_t off_stride;    // entries per row of chunk_off = 2^c2 + 1
+    uint32_t key_parts, key_part;   // KdfTable::key_parts: windows of other key-space slices are dropped in A0 / A1
     uint32_t dbg;           // experiments only (bucket kernel, plain-loop variant): 1 skip LDS insert, 4 skip write-back
 };
 
@@ -182,8 +183,9 @@ __global__ __launch_bounds__(KB_THREADS) void kb_hist1_kernel(
 #pragma unroll
         for (int u = 0; u < WPT; ++u) {
             uint64_t lo, hi; win.key(u, lo, hi);
-            const bool ok = (win.valid >> u) & 1;
-            const uint32_t bin = ok ? kb_coarse(plan, kdf_hash(lo, hi)) : (uint32_t)(1 << KB_C1_MAX);   // dummy counter
+            const uint64_t hsh = kdf_hash(lo, hi);
+            const bool ok = ((win.valid >> u) & 1) && (plan.key_parts <= 1 || kdf_slice(hsh, plan.key_parts) == plan.key_part);
+            const uint32_t bin = ok ? kb_coarse(plan, hsh) : (uint32_t)(1 << KB_C1_MAX);   // dummy counter
             atomicAdd(&hist[bin], 1u);
         }
     }
@@ -299,8 +301,9 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
         for (int u = 0; u < WPT; ++u) {
             uint64_t lo, hi; win.key(u, lo, hi);
             klo[u] = lo; if constexpr (KW == 2) khi[u] = hi;
-            const bool ok = (win.valid >> u) & 1;
-            const uint32_t bin = ok ? kb_coarse(plan, kdf_hash(lo, hi)) : (uint32_t)DUMMY;
+            const uint64_t hsh = kdf_hash(lo, hi);
+            const bool ok = ((win.valid >> u) & 1) && (plan.key_parts <= 1 || kdf_slice(hsh, plan.key_parts) == plan.key_part);
+            const uint32_t bin = ok ? kb_coarse(plan, hsh) : (uint32_t)DUMMY;
             br[u] = bin << 16;
         }
 #pragma unroll

@@ -52,7 +52,19 @@ struct KdfTable {
     uint32_t *cnt;
     uint32_t log2cap;
     uint32_t bucket_bits;  // <= log2cap
+    // Counting in key-space slices ("key_parts" option): an INSERT-mode count only takes the windows whose key
+    // belongs to slice key_part of key_parts (kdf_slice below), so a sample whose distinct k-mers do not fit
+    // one table is counted in several passes over the same stream.
+    uint32_t key_parts;    // 0 or 1: everything
+    uint32_t key_part;
 };
+
+// Slice of a key from the LOW 16 bits of its hash.  (The multi-GPU owner function uses the TOP bits, which are
+// the top bits of the home slot: owners are contiguous slot ranges, ideal for the owner-ordered dump and exactly
+// wrong here -- a slice must spread over the whole table, or the table would be 1/parts full when it overflows.)
+__host__ __device__ __forceinline__ uint32_t kdf_slice(uint64_t hash, uint32_t parts) {
+    return (uint32_t)(((hash & 0xFFFFu) * parts) >> 16);
+}
 
 struct KdfCtl {            // device-resident control block (one per engine)
     unsigned long long distinct[KDF_SHARDS * 16];  // one 128-B line per shard

@@ -39,8 +39,9 @@ __global__ __launch_bounds__(256) void kdf_stream_kernel(
     bool full = false;
     if (active) {
         const uint64_t m0 = invalid[tile], m1 = invalid[tile + 1];
-        const uint64_t valid = kdf_valid_windows(m0, m1, k);
+        uint64_t valid = kdf_valid_windows(m0, m1, k);
         nwin = __popcll(valid);
+        const bool sliced = MODE == MODE_INSERT && t.key_parts > 1;       // count only this key-space slice (KdfTable::key_parts)
         uint64_t hits = 0;
         if (valid) {
             constexpr int NW = KW == 1 ? 3 : 4;
@@ -60,7 +61,9 @@ __global__ __launch_bounds__(256) void kdf_stream_kernel(
                     } else {
                         kdf_window_wide((const uint64_t (&)[4])w, b + u, k, klo[u], khi[u]);
                     }
-                    slot[u] = kdf_home(t, kdf_hash(klo[u], khi[u]));
+                    const uint64_t hsh = kdf_hash(klo[u], khi[u]);
+                    slot[u] = kdf_home(t, hsh);
+                    if (sliced && ((valid >> (b + u)) & 1) && kdf_slice(hsh, t.key_parts) != t.key_part) { valid &= ~(1ull << (b + u)); --nwin; }
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -252,6 +255,7 @@ struct kdf_engine {
     unsigned long long *kb_totals_host = nullptr;   // pinned [4]
     void *kb_buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ent_lo, ent_hi, chunk_off, failed, hist_wg, wg_base
     size_t kb_bytes[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t opt_key_parts = 0, opt_key_part = 0;    // count only one slice of the key space (KdfTable::key_parts)
     uint64_t opt_binned_min_positions = 1ull << 22;  // smaller batches use the direct global-table kernels
     uint64_t opt_binned_max_positions = 1ull << 31;  // longer streams are walked in several binned passes: a pass must add
                                                      // < 2^32 to any slot (kernel C saturates by comparing with the HBM count)
@@ -390,6 +394,7 @@ static int table_rehash(kdf_engine *h, uint32_t new_log2) {
     if (full) { table_free(nt); return fail(h, KDF_ERR_TABLE_FULL, "rehash: bucket overflow at 2^%u slots", new_log2); }
     table_free(h->t);
     h->t = nt;
+    h->t.key_parts = h->opt_key_parts; h->t.key_part = h->opt_key_part;
     h->cap = 1ull << new_log2;
     // restore the window counter (host-side accumulation)
     h->windows = windows;
@@ -514,6 +519,7 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     if (n_tiles == 0) return KDF_OK;
     KbPlan plan = kb_make_plan(h->t);
     plan.dbg = h->opt_debug_flags;
+    plan.key_parts = filtered ? 0 : h->t.key_parts; plan.key_part = h->t.key_part;
     const int nb1 = 1 << KB_C1_MAX;
     if (!h->kb_small) {
         HIPCHK(h, hipMalloc((void **)&h->kb_small, (size_t)(4 * (nb1 + 1) + 16) * 8));
@@ -628,6 +634,7 @@ static bool use_binned(const kdf_engine *h, uint64_t n_bases, bool filtered) {
 // at load <= 0.8; the table doubles when fewer than cap/8 positions fit.
 static int count_insert_dev(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases) {
     if (h->filter_mode) return fail(h, KDF_ERR_STATE, "kdf_count_reads: a filter is loaded; call kdf_clear first");
+    h->t.key_parts = h->opt_key_parts; h->t.key_part = h->opt_key_part;       // (tables are re-created by reserve / rehash: set per call)
     const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
     if (use_binned(h, n_bases, false)) {
         int rc = kb_passes(h, d_packed, d_invalid, n_bases, false);
@@ -1190,7 +1197,13 @@ int kdf_profile_read(kdf_engine *h, double *kernel_ms, uint64_t *launches, uint6
 int kdf_set_option(kdf_engine *h, const char *name, int64_t value) {
     if (!h || !name) return fail(h, KDF_ERR_INVALID, "kdf_set_option: NULL argument");
     const std::string n(name);
-    if (n == "binned_min_positions") h->opt_binned_min_positions = (uint64_t)value;
+    if (n == "key_parts" || n == "key_part") {
+        const uint32_t parts = n == "key_parts" ? (uint32_t)value : h->opt_key_parts, part = n == "key_part" ? (uint32_t)value : h->opt_key_part;
+        if (value < 0 || parts > 65536 || (n == "key_part" && part >= std::max<uint32_t>(parts, 1)))
+            return fail(h, KDF_ERR_INVALID, "key_parts must be 0..65536 and key_part below it");
+        h->opt_key_parts = parts; h->opt_key_part = n == "key_parts" ? 0 : part;
+    }
+    else if (n == "binned_min_positions") h->opt_binned_min_positions = (uint64_t)value;
     else if (n == "binned_max_positions") {
         if (value < KDF_TILE || value > (1ll << 31)) return fail(h, KDF_ERR_INVALID, "binned_max_positions must be in [64, 2^31]");
         h->opt_binned_max_positions = (uint64_t)value / KDF_TILE * KDF_TILE;      // passes start on tile boundaries

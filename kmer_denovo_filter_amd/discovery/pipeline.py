@@ -45,15 +45,27 @@ def _extract_child_kmers_discovery(child_bam, ref_fasta, kmer_size, min_child_co
     logger.info("Extracting child k-mers from BAM (k=%d, jf hash size=%s)…", kmer_size, jf_hash_size)
     extract_start = time.monotonic()
     child_candidates_fa = os.path.join(tmpdir, "child_candidates.fa")
+    # A 30x human sample has ~10^10 distinct 31-mers (sequencing errors included): more than one table in
+    # 288 GB of HBM holds.  KDF_KEY_PARTS = P counts the key space in P slices, one pass over the BAM each
+    # (Jellyfish's answer to the same problem is to spill and merge hash files, jellyfish_wrappers.py:335-366).
+    parts = max(1, int(os.environ.get("KDF_KEY_PARTS", "1")))
     try:
-        with KmerEngine(kmer_size, capacity_hint=_engine_capacity_hint(jf_hash_size, child_bam)) as eng:
-            _stream_bam(eng, child_bam, ref_fasta, threads, filtered=False)
-            cap, distinct, windows = eng.stats()
-            logger.info("Child k-mer counting complete (%s, %d windows, %d distinct, table %d slots)",
-                        _format_elapsed(time.monotonic() - extract_start), windows, distinct, cap)
-            logger.info("Dumping child k-mers with count >= %d…", min_child_count)
-            dump_start = time.monotonic()
-            lo, hi, _ = eng.export_ge(min_child_count)
+        with KmerEngine(kmer_size, capacity_hint=max(1, _engine_capacity_hint(jf_hash_size, child_bam) // parts)) as eng:
+            los, his = [], []
+            if parts > 1:
+                eng.set_option("key_parts", parts)
+            for part in range(parts):
+                if parts > 1:
+                    eng.clear(); eng.set_option("key_part", part)
+                _stream_bam(eng, child_bam, ref_fasta, threads, filtered=False)
+                cap, distinct, windows = eng.stats()
+                logger.info("Child k-mer counting complete (%s, slice %d of %d, %d windows, %d distinct, table %d slots)",
+                            _format_elapsed(time.monotonic() - extract_start), part + 1, parts, windows, distinct, cap)
+                logger.info("Dumping child k-mers with count >= %d…", min_child_count)
+                dump_start = time.monotonic()
+                lo, hi, _ = eng.export_ge(min_child_count)
+                los.append(lo); his.append(hi)
+            lo, hi = (np.concatenate(los), np.concatenate(his)) if parts > 1 else (los[0], his[0])
     except KdfError as e:
         raise RuntimeError(f"jellyfish count (child) failed: {e}") from e
     n_candidates = write_kmer_fasta(child_candidates_fa, lo, hi, kmer_size)

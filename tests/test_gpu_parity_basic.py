@@ -244,3 +244,40 @@ def test_counts_saturate_at_uint32_max(oracle, k, path):
             glo, ghi, gcnt = e.export_ge(0)
             exp = cnt.astype(np.uint64).copy(); exp[a_idx] += int(pre[0]); exp[other] += int(pre[1])
             np.testing.assert_array_equal(gcnt, np.minimum(exp, 0xFFFFFFFF).astype(np.uint32))
+
+
+@pytest.mark.parametrize("k,path", [(31, 1), (31, 2), (47, 2)])
+def test_count_in_key_space_slices(oracle, k, path):
+    """"key_parts" / "key_part": a sample whose distinct k-mers do not fit one table is counted slice by slice
+    over the same stream.  The slices partition the key space (ranges of the low hash bits), so their dumps are
+    disjoint, their union is the full count, and their window totals add up -- also when the table has to grow
+    in the middle of a slice."""
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+
+    def slice_of(lo_, hi_, parts):                         # kdf_slice(kdf_hash(lo, hi), parts) of csrc/kdf_device.h
+        M = (1 << 64) - 1
+        x = lo_ ^ (((hi_ << 37) | (hi_ >> 27)) & M)
+        h = ((x ^ (x >> 32)) * 0x9E3779B97F4A7C15) & M
+        return ((h & 0xFFFF) * parts) >> 16
+    rng = np.random.default_rng(21)
+    genome = rng.integers(0, 4, 60_000).astype(np.uint8)
+    reads = rand_reads(rng, 1500, 40, 300, genome=genome) + ["A" * 200] * 5
+    st = ReadStream.from_strings(reads)
+    t, (lo, hi, cnt) = oracle_sorted(oracle, k, reads)
+    total_windows = oracle.count_windows(reads, k)
+    for parts in (2, 5):
+        got, windows = {}, 0
+        with KmerEngine(k, capacity_hint=1 << 9) as e:                       # small: every slice grows the table
+            e.set_option("force_path", path); e.set_option("key_parts", parts)
+            for p in range(parts):
+                e.clear(); e.set_option("key_part", p)
+                e.count(st)
+                glo, ghi, gcnt = e.export_ge(0)
+                windows += e.stats()[2]
+                for a, b, c in zip(glo.tolist(), ghi.tolist(), gcnt.tolist()):
+                    assert (b, a) not in got and slice_of(a, b, parts) == p
+                    got[(b, a)] = c
+            with pytest.raises(Exception):
+                e.set_option("key_part", parts)
+        assert windows == total_windows
+        assert got == {(int(b), int(a)): int(c) for a, b, c in zip(lo, hi, cnt)}

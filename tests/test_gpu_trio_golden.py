@@ -69,6 +69,18 @@ def test_discovery_chain_goldens(oracle, trio_reads, discovery):
         np.testing.assert_array_equal(got, st[stage][0])
 
 
+def test_child_extraction_in_key_space_slices(discovery, tmp_path, monkeypatch):
+    """KDF_KEY_PARTS: the child count done in three slices of the key space (three passes over the BAM)
+    yields the same candidate set as the single pass."""
+    from kmer_denovo_filter_amd.discovery.pipeline import _extract_child_kmers_discovery
+    from kmer_denovo_filter_amd.kmer_fasta import read_kmer_fasta_keys
+    monkeypatch.setenv("KDF_KEY_PARTS", "3")
+    fa, n = _extract_child_kmers_discovery(os.path.join(GIAB, "HG002_child.bam"), None, 31, 3, 4, str(tmp_path))
+    assert n == 51125
+    lo, _ = read_kmer_fasta_keys(fa, 31)
+    np.testing.assert_array_equal(np.sort(lo), np.sort(discovery["candidates"][1][0]))
+
+
 def test_intermediate_fasta_contract(discovery):
     lines = open(discovery["proband_fa"]).read().split("\n")
     assert lines[0] == ">0" and lines[2] == ">1" and len(lines[1]) == 31
