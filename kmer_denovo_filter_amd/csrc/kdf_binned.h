@@ -163,7 +163,7 @@ struct KbWindows {
 // A0: persistent workgroups.  Workgroup w owns slabs [w*spw, (w+1)*spw) in BOTH
 // passes; it accumulates its coarse-bin histogram in LDS over all its slabs and
 // writes ONE row hist_wg[w][bin] (no global atomics).
-template <int KW>
+template <int KW, bool SLICED>
 __global__ __launch_bounds__(KB_THREADS) void kb_hist1_kernel(
     const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid, uint64_t n_tiles, int k,
     KbPlan plan, KbScratch s, uint32_t slabs_per_wg)
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_hist1_kernel(
         for (int u = 0; u < WPT; ++u) {
             uint64_t lo, hi; win.key(u, lo, hi);
             const uint64_t hsh = kdf_hash(lo, hi);
-            const bool ok = ((win.valid >> u) & 1) && (plan.key_parts <= 1 || kdf_slice(hsh, plan.key_parts) == plan.key_part);
+            const bool ok = ((win.valid >> u) & 1) && (!SLICED || kdf_slice(hsh, plan.key_parts) == plan.key_part);
             const uint32_t bin = ok ? kb_coarse(plan, hsh) : (uint32_t)(1 << KB_C1_MAX);   // dummy counter
             atomicAdd(&hist[bin], 1u);
         }
@@ -246,7 +246,7 @@ __device__ __forceinline__ void kb_lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int KW>
+template <int KW, bool SLICED>
 __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
     const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid, uint64_t n_tiles, int k,
     KbPlan plan, KbScratch s, uint32_t slabs_per_wg)
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
             uint64_t lo, hi; win.key(u, lo, hi);
             klo[u] = lo; if constexpr (KW == 2) khi[u] = hi;
             const uint64_t hsh = kdf_hash(lo, hi);
-            const bool ok = ((win.valid >> u) & 1) && (plan.key_parts <= 1 || kdf_slice(hsh, plan.key_parts) == plan.key_part);
+            const bool ok = ((win.valid >> u) & 1) && (!SLICED || kdf_slice(hsh, plan.key_parts) == plan.key_part);
             const uint32_t bin = ok ? kb_coarse(plan, hsh) : (uint32_t)DUMMY;
             br[u] = bin << 16;
         }

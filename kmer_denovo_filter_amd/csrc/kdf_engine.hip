@@ -477,7 +477,8 @@ static KbPlan kb_make_plan(const KdfTable &t) {
 
 template <int KW>
 static int kb_set_lds_attrs(kdf_engine *h, size_t a1, size_t b, size_t c) {
-    HIPCHK(h, hipFuncSetAttribute((const void *)kb_scatter1_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a1));
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_scatter1_kernel<KW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a1));
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_scatter1_kernel<KW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a1));
     HIPCHK(h, hipFuncSetAttribute((const void *)kb_finesort_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b));
     HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_INSERT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c));
     HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_FILTERED, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c));
@@ -551,7 +552,9 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     if ((rc = kb_reserve(h, 4, (size_t)grid_a * nbins * 4))) return rc;
     if ((rc = kb_reserve(h, 5, (size_t)grid_a * nbins * 4))) return rc;
     s.hist_wg = (uint32_t *)h->kb_buf[4]; s.wg_base = (uint32_t *)h->kb_buf[5];
-    hipLaunchKernelGGL(kb_hist1_kernel<KW>, dim3(grid_a), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
+    const bool sliced = plan.key_parts > 1;
+    if (sliced) hipLaunchKernelGGL((kb_hist1_kernel<KW, true>), dim3(grid_a), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
+    else hipLaunchKernelGGL((kb_hist1_kernel<KW, false>), dim3(grid_a), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
     hipLaunchKernelGGL(kb_colscan_kernel, dim3(nbins), dim3(256), 0, h->stream, plan, s, (uint32_t)grid_a);
     hipLaunchKernelGGL(kb_scan1_kernel, dim3(1), dim3(KB_THREADS), 0, h->stream, plan, s, (uint32_t)CHUNK, h->ctl);
     HIPCHK(h, hipGetLastError());
@@ -570,7 +573,8 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     s.chunk_off = (uint32_t *)h->kb_buf[2]; s.failed = (uint32_t *)h->kb_buf[3];
     HIPCHK(h, hipMemsetAsync(s.failed, 0, failed_bytes, h->stream));
 
-    hipLaunchKernelGGL(kb_scatter1_kernel<KW>, dim3(grid_a), dim3(KB_THREADS), lds_a1, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
+    if (sliced) hipLaunchKernelGGL((kb_scatter1_kernel<KW, true>), dim3(grid_a), dim3(KB_THREADS), lds_a1, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
+    else hipLaunchKernelGGL((kb_scatter1_kernel<KW, false>), dim3(grid_a), dim3(KB_THREADS), lds_a1, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
     stamp();                                                   // end of A1
     hipLaunchKernelGGL(kb_finesort_kernel<KW>, dim3((unsigned)n_chunks), dim3(KB_THREADS), lds_b, h->stream, plan, s);
     stamp();                                                   // end of B

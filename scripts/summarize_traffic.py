@@ -38,7 +38,7 @@ write, nw = per_kernel("write", "WRITE_SIZE")
 bench = json.load(open(os.path.join(out, "fetch", "bench.json")))
 cfg = bench["config"]
 n_entries = cfg["windows_per_gpu"]
-names = ("kb_hist1_kernel<1>", "kb_scatter1_kernel<1>", "kb_finesort_kernel<1>", "kb_bucket_kernel<1, 0")   # prefixes of the pass kernels
+names = ("kb_hist1_kernel<1", "kb_scatter1_kernel<1", "kb_finesort_kernel<1>", "kb_bucket_kernel<1, 0")   # prefixes of the pass kernels
 rows, total = [], 0.0
 for k in sorted(set(fetch) | set(write)):
     if not (k.startswith("kb_") or k.startswith("kdf_")):
