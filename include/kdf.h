@@ -88,6 +88,8 @@ int kdf_stats(kdf_engine *h, uint64_t *capacity, uint64_t *distinct, uint64_t *w
  *            binned pass, <= 2^31: longer streams take several passes); "binned_filtered_min_log2cap"
  *   stats    "binned_passes", "replayed_buckets", "log2cap", "bucket_bits" */
 int kdf_set_option(kdf_engine *h, const char *name, int64_t value);
+/* Free / total HBM of a device (hipMemGetInfo): the child-count mirror sizes "key_parts" with it. */
+int kdf_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 int kdf_get_stat(kdf_engine *h, const char *name, int64_t *value);
 
 /* Measurement hook (bench.py): when enabled, every launch of the dominant

@@ -60,6 +60,7 @@ SYMBOLS = [
                                     POINTER(c_char_p), POINTER(POINTER(c_int64))]),
     ("kdf_reader_last_quals", c_int, [_P, POINTER(POINTER(ctypes.c_uint8)), POINTER(POINTER(c_int64)),
                                       POINTER(POINTER(ctypes.c_uint8))]),
+    ("kdf_device_memory", c_int, [c_int, POINTER(c_uint64), POINTER(c_uint64)]),
     ("kdf_reader_last_ordinals", c_int, [_P, POINTER(POINTER(c_uint64))]),
     ("kdf_bam_write_subset", c_int, [c_char_p, c_char_p, _P, c_uint64, _P, _P, c_int, c_int, POINTER(c_uint64)]),
     ("kdf_reader_ref_count", c_int, [_P]),

@@ -1033,6 +1033,16 @@ int kdf_export_parts_dev(kdf_engine *h, uint32_t min_count, uint32_t parts, void
     return KDF_OK;
 }
 
+int kdf_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
+    if (!free_bytes || !total_bytes) return fail(nullptr, KDF_ERR_INVALID, "kdf_device_memory: NULL pointer");
+    size_t f = 0, t = 0;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMemGetInfo(&f, &t);
+    if (e != hipSuccess) return fail(nullptr, KDF_ERR_HIP, "kdf_device_memory: %s", hipGetErrorString(e));
+    *free_bytes = f; *total_bytes = t;
+    return KDF_OK;
+}
+
 int kdf_count_ge(kdf_engine *h, uint32_t min_count, uint64_t *n_out) {
     if (!h || !n_out) return fail(h, KDF_ERR_INVALID, "kdf_count_ge: NULL pointer");
     HIPCHK(h, hipSetDevice(h->device));

@@ -35,6 +35,22 @@ from ..kmer_fasta import read_kmer_fasta_keys, remove_with_sidecar, write_kmer_f
 logger = logging.getLogger(__name__)
 
 
+def _child_key_parts(child_bam, device=0):
+    """Slices of the key space for the child count: ``KDF_KEY_PARTS`` when set, else from the BAM size and
+    the free HBM.  Rule of thumb (30x human WGS: ~0.6 BAM bytes per base, ~0.14 distinct 31-mers per base with
+    0.5 % errors): distinct ~ 0.23 x BAM bytes, table bytes ~ 12 x distinct / 0.6 ~ 4.6 x BAM bytes; the table
+    may take 70 % of what is free (the rest is partition scratch and growth).  Small inputs give 1."""
+    env = os.environ.get("KDF_KEY_PARTS")
+    if env:
+        return max(1, int(env))
+    from ctypes import byref, c_uint64
+    from .. import _native
+    free, total = c_uint64(0), c_uint64(0)
+    _native.check(_native.load().kdf_device_memory(device, byref(free), byref(total)))
+    need = 4.6 * os.path.getsize(child_bam)
+    return max(1, int(-(-need // max(1.0, 0.7 * free.value))))
+
+
 def _extract_child_kmers_discovery(child_bam, ref_fasta, kmer_size, min_child_count, threads, tmpdir,
                                    jf_hash_size=None):
     """Module 1: count every canonical child k-mer, keep count >= min_child_count.
@@ -48,7 +64,7 @@ def _extract_child_kmers_discovery(child_bam, ref_fasta, kmer_size, min_child_co
     # A 30x human sample has ~10^10 distinct 31-mers (sequencing errors included): more than one table in
     # 288 GB of HBM holds.  KDF_KEY_PARTS = P counts the key space in P slices, one pass over the BAM each
     # (Jellyfish's answer to the same problem is to spill and merge hash files, jellyfish_wrappers.py:335-366).
-    parts = max(1, int(os.environ.get("KDF_KEY_PARTS", "1")))
+    parts = _child_key_parts(child_bam)
     try:
         with KmerEngine(kmer_size, capacity_hint=max(1, _engine_capacity_hint(jf_hash_size, child_bam) // parts)) as eng:
             los, his = [], []

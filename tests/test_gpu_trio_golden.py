@@ -275,3 +275,14 @@ def test_informative_reads_bam_vcf_mode(tmp_path):
     for key, rn in by_var.items():
         assert raw.count(key.encode()) >= len(rn)
     assert os.path.exists(out + ".bai")
+
+
+def test_child_key_parts_rule(tmp_path, monkeypatch):
+    """Automatic choice of KDF_KEY_PARTS: one pass for the fixture, several for a BAM too large for the free HBM."""
+    from kmer_denovo_filter_amd.discovery import pipeline as P
+    monkeypatch.delenv("KDF_KEY_PARTS", raising=False)
+    assert P._child_key_parts(os.path.join(GIAB, "HG002_child.bam")) == 1
+    monkeypatch.setattr(os.path, "getsize", lambda p: 400 << 30)                 # a 400 GB BAM
+    assert P._child_key_parts("whatever.bam") >= 7                               # 1.8 TB of table on <= 288 GB
+    monkeypatch.setenv("KDF_KEY_PARTS", "5")
+    assert P._child_key_parts("whatever.bam") == 5
