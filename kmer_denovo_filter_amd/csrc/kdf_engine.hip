@@ -308,9 +308,21 @@ static int table_alloc(kdf_engine *h, uint32_t log2cap, KdfTable &t) {
     t = KdfTable{};
     t.log2cap = log2cap;
     t.bucket_bits = std::min<uint32_t>(log2cap, h->kw == 1 ? 12 : 11);   // 48 / 40 KB of LDS per bucket
-    HIPCHK(h, hipMalloc((void **)&t.lo, cap * 8));
-    if (h->kw == 2) HIPCHK(h, hipMalloc((void **)&t.hi, cap * 8));
-    HIPCHK(h, hipMalloc((void **)&t.cnt, cap * 4));
+    {
+        hipError_t e = hipMalloc((void **)&t.lo, cap * 8);
+        if (e == hipSuccess && h->kw == 2) e = hipMalloc((void **)&t.hi, cap * 8);
+        if (e == hipSuccess) e = hipMalloc((void **)&t.cnt, cap * 4);
+        if (e != hipSuccess) {
+            if (t.lo) (void)hipFree(t.lo);
+            if (t.hi) (void)hipFree(t.hi);
+            t = KdfTable{};
+            (void)hipGetLastError();
+            return fail(h, e == hipErrorOutOfMemory ? KDF_ERR_NOMEM : KDF_ERR_HIP,
+                        "a table of 2^%u slots (%.1f GB) does not fit the device (%s): count the sample in key-space "
+                        "slices (option key_parts / key_part; KDF_KEY_PARTS for the child count)",
+                        log2cap, (double)cap * (8.0 * h->kw + 4.0) / 1e9, hipGetErrorString(e));
+        }
+    }
     HIPCHK(h, hipMemsetAsync(t.lo, 0xFF, cap * 8, h->stream));
     if (h->kw == 2) HIPCHK(h, hipMemsetAsync(t.hi, 0xFF, cap * 8, h->stream));
     HIPCHK(h, hipMemsetAsync(t.cnt, 0, cap * 4, h->stream));

@@ -281,3 +281,14 @@ def test_count_in_key_space_slices(oracle, k, path):
                 e.set_option("key_part", parts)
         assert windows == total_windows
         assert got == {(int(b), int(a)): int(c) for a, b, c in zip(lo, hi, cnt)}
+
+
+def test_table_too_large_is_a_clear_error():
+    """Out of device memory names the way out (key-space slices) instead of a bare HIP error."""
+    from kmer_denovo_filter_amd import KmerEngine
+    from kmer_denovo_filter_amd._native import KdfError
+    with pytest.raises(KdfError) as ei:
+        KmerEngine(31, capacity_hint=1 << 40)            # 2^41 slots = 26 TB
+    assert "key_parts" in str(ei.value) and "does not fit" in str(ei.value)
+    with KmerEngine(31, capacity_hint=1 << 10) as e:      # the process is still usable afterwards
+        assert e.stats()[1] == 0
