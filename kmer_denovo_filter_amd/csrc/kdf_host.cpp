@@ -1195,10 +1195,13 @@ int kdf_bam_write_subset(const char *src_bam, const char *dst_bam, const uint64_
     w.flush_block();                                             // records start on a block boundary, as htslib writes them
     std::vector<RefIndex> idx(ref_lens.size());
     uint64_t n_no_coor = 0;
+    uint64_t prev_end = w.tell();
     for (auto &x : recs) {
-        // keep a record inside one block when it fits (htslib does the same)
+        // keep a record inside one block when it fits (htslib does the same).  The index takes the offset
+        // where the PREVIOUS record ended as this record's start, as hts_idx_push is fed: a run of one bin
+        // then stays one chunk across block boundaries (a reader landing on a block's end moves on to the next).
         if (w.buf.size() + 4 + x.raw.size() > BgzfWriter::BLOCK && !w.buf.empty()) w.flush_block();
-        const uint64_t vo0 = w.tell();
+        const uint64_t vo0 = prev_end;
         uint8_t bs[4]; const uint32_t l = (uint32_t)x.raw.size();
         for (int i = 0; i < 4; ++i) bs[i] = (uint8_t)(l >> (8 * i));
         const uint8_t *p = x.raw.data();
@@ -1216,7 +1219,7 @@ int kdf_bam_write_subset(const char *src_bam, const char *dst_bam, const uint64_
         x.raw[10] = (uint8_t)(bin & 0xff); x.raw[11] = (uint8_t)(bin >> 8);
         w.write(bs, 4);
         w.write(x.raw.data(), x.raw.size());
-        const uint64_t vo1 = w.tell();
+        const uint64_t vo1 = prev_end = w.tell();
         if (!sort_and_index) continue;
         if (tid < 0 || (size_t)tid >= idx.size() || pos < 0) { ++n_no_coor; continue; }
         RefIndex &ri = idx[(size_t)tid];
@@ -1236,6 +1239,35 @@ int kdf_bam_write_subset(const char *src_bam, const char *dst_bam, const uint64_
         std::vector<uint8_t> b = {'B', 'A', 'I', 1};
         put32(b, (uint32_t)idx.size());
         for (auto &ri : idx) {
+            // htslib's compress_binning (hts.c): a bin whose chunks span less than 64 KB of the file is merged
+            // into its parent bin when that parent exists, deepest level first; then chunks that touch the same
+            // BGZF block are joined.  Queries are unaffected (parents are always searched); samtools' own
+            // indexes look like this, and so do ours.
+            for (int l = 5; l > 0; --l) {
+                const uint32_t first = ((1u << (3 * l)) - 1) / 7;
+                for (auto it = ri.bins.begin(); it != ri.bins.end();) {
+                    const uint32_t key = it->first;
+                    auto &pl = it->second;
+                    if (key < first || key >= 37449 || pl.empty()) { ++it; continue; }
+                    if (l < 5 && pl.size() > 1) std::sort(pl.begin(), pl.end());
+                    if ((pl.back().second >> 16) - (pl.front().first >> 16) < 0x10000) {
+                        auto parent = ri.bins.find((key - 1) >> 3);
+                        if (parent == ri.bins.end()) { ++it; continue; }
+                        parent->second.insert(parent->second.end(), pl.begin(), pl.end());
+                        it = ri.bins.erase(it);
+                    } else ++it;
+                }
+            }
+            for (auto &kv : ri.bins) {
+                auto &pl = kv.second;
+                std::sort(pl.begin(), pl.end());
+                size_t m = 0;
+                for (size_t q = 1; q < pl.size(); ++q) {
+                    if ((pl[m].second >> 16) >= (pl[q].first >> 16)) { if (pl[m].second < pl[q].second) pl[m].second = pl[q].second; }
+                    else pl[++m] = pl[q];
+                }
+                if (!pl.empty()) pl.resize(m + 1);
+            }
             put32(b, (uint32_t)(ri.bins.size() + (ri.any ? 1 : 0)));
             for (auto &kv : ri.bins) {
                 put32(b, kv.first); put32(b, (uint32_t)kv.second.size());
