@@ -324,3 +324,92 @@ int kdfo_count_reads_mt(void *h, const char *buf, const int64_t *offs, int64_t n
     free(jobs); free(th);
     return 0;
 }
+
+/* CPU baseline leg proper (bench.py): the same count as kdfo_count_reads followed by the
+ * `dump -L min_count` tally, organised the way a multi-core counter would be: phase 1, every
+ * thread takes a contiguous share of the reads and deals its canonical k-mers into one buffer
+ * per key partition (hash % T); phase 2, thread p counts partition p in a map of its own.  No
+ * locks, every window is extracted once, nothing is merged: out[0] = distinct k-mers, out[1] =
+ * sum of the counts (= valid windows), out[2] = k-mers with count >= min_count.
+ * tests/test_oracle_golden.py holds it to kdfo_count_reads + kdfo_export_ge. */
+typedef struct { u128 *v; int64_t n, cap; } kbuf;
+typedef struct {
+    const char *buf; const int64_t *offs; int64_t r0, r1; int k, tid, T;
+    kbuf *out;                 /* phase 1: T buffers of this thread */
+    kbuf **all;                /* phase 2: all[t] = thread t's buffers */
+    uint32_t min_count; uint64_t res[3]; int err;
+} deal_job;
+static void cb_deal(u128 c, int64_t pos, void *ctx) {
+    (void)pos; deal_job *j = (deal_job *)ctx;
+    kbuf *b = &j->out[(hkey(c) >> 40) % (uint64_t)j->T];
+    if (b->n == b->cap) {
+        int64_t nc = b->cap ? b->cap * 2 : 4096;
+        u128 *nv = (u128 *)realloc(b->v, (size_t)nc * sizeof(u128));
+        if (!nv) { j->err = 1; return; }
+        b->v = nv; b->cap = nc;
+    }
+    b->v[b->n++] = c;
+}
+static void *deal_run(void *arg) {
+    deal_job *j = (deal_job *)arg;
+    for (int64_t r = j->r0; r < j->r1 && !j->err; r++)
+        for_each_window(j->buf + j->offs[r], j->offs[r + 1] - j->offs[r], j->k, cb_deal, j);
+    return NULL;
+}
+static void *tally_run(void *arg) {
+    deal_job *j = (deal_job *)arg;
+    int64_t total = 0;
+    for (int t = 0; t < j->T; t++) total += j->all[t][j->tid].n;
+    kmap m;
+    if (kmap_init(&m, (uint64_t)(total / 2 + 16)) != 0) { j->err = 1; return NULL; }
+    for (int t = 0; t < j->T; t++) {
+        const kbuf *b = &j->all[t][j->tid];
+        for (int64_t i = 0; i < b->n; i++) {
+            uint64_t s = kmap_find(&m, b->v[i], 1);
+            if (m.vals[s] != UINT32_MAX) m.vals[s]++;
+        }
+    }
+    j->res[0] = m.n; j->res[1] = 0; j->res[2] = 0;
+    for (uint64_t s = 0; s < m.cap; s++)
+        if (m.used[s]) { j->res[1] += m.vals[s]; if (m.vals[s] >= j->min_count) j->res[2]++; }
+    kmap_free(&m);
+    return NULL;
+}
+int kdfo_count_tally_mt(const char *buf, const int64_t *offs, int64_t n_reads, int k, int threads,
+                        uint32_t min_count, uint64_t *out) {
+    if (k < 1 || k > 64) return -1;
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    const int T = threads;
+    deal_job *jobs = (deal_job *)calloc(T, sizeof(deal_job));
+    pthread_t *th = (pthread_t *)calloc(T, sizeof(pthread_t));
+    kbuf **all = (kbuf **)calloc(T, sizeof(kbuf *));
+    int err = 0;
+    for (int t = 0; t < T; t++) {
+        all[t] = (kbuf *)calloc(T, sizeof(kbuf));
+        jobs[t].buf = buf; jobs[t].offs = offs; jobs[t].k = k; jobs[t].tid = t; jobs[t].T = T;
+        jobs[t].r0 = n_reads * t / T; jobs[t].r1 = n_reads * (t + 1) / T;
+        jobs[t].out = all[t]; jobs[t].all = all; jobs[t].min_count = min_count;
+        /* buffers sized for an even deal up front (they still grow if the deal is uneven) */
+        const int64_t share = (offs[jobs[t].r1] - offs[jobs[t].r0]) / T;
+        for (int p = 0; p < T; p++) {
+            all[t][p].cap = share + share / 8 + 4096;
+            all[t][p].v = (u128 *)malloc((size_t)all[t][p].cap * sizeof(u128));
+            if (!all[t][p].v) { all[t][p].cap = 0; }
+        }
+    }
+    for (int t = 0; t < T; t++) pthread_create(&th[t], NULL, deal_run, &jobs[t]);
+    for (int t = 0; t < T; t++) { pthread_join(th[t], NULL); err |= jobs[t].err; }
+    if (!err) {
+        for (int t = 0; t < T; t++) pthread_create(&th[t], NULL, tally_run, &jobs[t]);
+        for (int t = 0; t < T; t++) { pthread_join(th[t], NULL); err |= jobs[t].err; }
+    }
+    out[0] = out[1] = out[2] = 0;
+    for (int t = 0; t < T; t++) {
+        for (int q = 0; q < 3; q++) out[q] += jobs[t].res[q];
+        for (int p = 0; p < T; p++) free(all[t][p].v);
+        free(all[t]);
+    }
+    free(all); free(jobs); free(th);
+    return err ? -1 : 0;
+}

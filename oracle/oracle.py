@@ -73,6 +73,7 @@ def _load():
     lib.kdfo_export_ge.restype = i64
     lib.kdfo_export_ge.argtypes = [vp, u32, vp, vp, vp]
     lib.kdfo_scan_reads.argtypes = [vp, vp, vp, i64, vp, vp]
+    lib.kdfo_count_tally_mt.argtypes = [vp, vp, i64, ci, ci, u32, vp]
     lib.kdfo_count_windows.restype = i64
     lib.kdfo_count_windows.argtypes = [vp, vp, i64, ci]
     _lib = lib
@@ -239,6 +240,16 @@ class OracleTable:
 def count_windows(reads, k: int) -> int:
     buf, offs = reads if isinstance(reads, tuple) else concat_reads(reads)
     return int(_load().kdfo_count_windows(_p(buf), _p(offs), len(offs) - 1, k))
+
+
+def count_tally_mt(reads, k: int, threads: int, min_count: int = 3):
+    """(distinct, sum of counts, k-mers with count >= min_count) of a full count of ``reads``:
+    the partitioned multi-core count that bench.py times as its CPU baseline."""
+    buf, offs = reads if isinstance(reads, tuple) else concat_reads(reads)
+    out = np.zeros(3, dtype=np.uint64)
+    if _load().kdfo_count_tally_mt(_p(buf), _p(offs), len(offs) - 1, k, threads, min_count, _p(out)) != 0:
+        raise MemoryError("oracle: kdfo_count_tally_mt failed")
+    return int(out[0]), int(out[1]), int(out[2])
 
 
 def canonical_key(kmer: str) -> int:

@@ -72,6 +72,21 @@ def test_jellyfish_fixture_bit_equal(oracle):
     t2 = oracle.OracleTable(31).count_reads([s for _, s in ref], threads=3)
     lo2, _, c2 = t2.export_ge(0)
     assert (lo2 == lo).all() and (c2 == c).all()
+    # and so does the partitioned count + tally that bench.py times as its CPU baseline
+    for threads in (1, 3, 8):
+        assert oracle.count_tally_mt([s for _, s in ref], 31, threads, 2) == (45275, 45804, int((counts >= 2).sum()))
+
+
+def test_partitioned_tally_equals_the_plain_count_on_the_child_reads(oracle, trio_reads):
+    """kdfo_count_tally_mt (the CPU baseline of bench.py) against kdfo_count_reads + kdfo_export_ge on the
+    golden child reads: 282 880 distinct 31-mers, 51 125 of them seen >= 3 times (metrics.json), and a
+    wide-key (k = 63) and a tiny-k case against the plain count."""
+    reads = trio_reads["child"]
+    d, total, ge3 = oracle.count_tally_mt(reads, 31, 4, 3)
+    assert (d, ge3) == (282880, 51125) and total == oracle.count_windows(reads, 31)
+    for k in (63, 5):
+        lo, hi, c = oracle.OracleTable(k).count_reads(reads).export_ge(0)
+        assert oracle.count_tally_mt(reads, k, 5, 3) == (len(lo), int(c.astype("int64").sum()), int((c >= 3).sum()))
 
 
 @pytest.fixture(scope="module")
