@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--genome", type=int, default=100_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N > 1 ranks on ONE GPU: gloo with host-staged collectives instead of RCCL "
                          "(checks the multi-GPU job end to end on a 1-GPU box; its timing means nothing)")
