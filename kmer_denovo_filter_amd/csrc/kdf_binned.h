@@ -28,7 +28,26 @@
 #define KB_F_BITS_MAX 9                  // used only when the table has more buckets than 2^(C1_MAX+8)
 #define KB_F         (1 << KB_F_BITS_MAX)  // LDS array size for the fine histogram
 #define KB_C1_MAX    10                  // coarse bins <= 1024
-#define KB_C_THREADS 512                 // bucket kernel
+// Bucket kernel: 768 threads = 12 waves per workgroup, two workgroups per CU (LDS) = 6 waves per SIMD,
+// which needs <= 80 VGPRs (amdgpu_waves_per_eu below; 78 used with 12 entries in flight per lane).  Measured on
+// the bench pass: 512 threads x 20 entries (4 waves per SIMD) 6.16 ms, 768 x 12 5.4 ms, 1024 x 8 (8 per SIMD,
+// spills) 6.0 ms; thread counts whose waves do not divide evenly over the four SIMDs (640, 896) leave one
+// workgroup per CU (9-10 ms).  12 x 768 = 9216 entries per batch also covers the bench's ~8.9 K entries per
+// bucket in one batch with 11.6 of the 12 waves busy.
+#ifndef KB_C_THREADS
+#define KB_C_THREADS 768
+#endif
+#ifndef KB_C_EPB_N
+#define KB_C_EPB_N 12                    // VAR 1, narrow keys: entries per thread and batch (a multiple of 4)
+#endif
+#ifndef KB_C_EPB_W
+#define KB_C_EPB_W 8                     // VAR 1, wide keys (4 measured the same, 12 spills)
+#endif
+#ifndef KB_C_WPE
+#define KB_C_WPE 6                       // waves per SIMD the register allocation aims at
+#endif
+static_assert(KB_C_EPB_N % 4 == 0 && KB_C_EPB_W % 4 == 0, "kernel C resolves entries four at a time");
+static_assert(KB_C_THREADS % 256 == 0 && KB_C_THREADS <= 1024, "whole waves on every SIMD");
 #define KB_C_RUNS    256                 // runs (chunks of the coarse bin) staged per round
 
 template <int KW> struct KbCfg;
@@ -518,10 +537,10 @@ __device__ __forceinline__ void kb_probe_wide_wave(uint64_t *tlo, uint64_t *thi,
 // barrier) and are probed densely, one per lane, after the batch.  Measured on the
 // bench pass: kernel C 7.6 -> 6.5 ms at k = 31, 16.0 -> 12.7 ms at k = 63.
 #define KB_C_LA    2                   // VAR 1: slots of the probe sequence read up front
-#define KB_C_QCAP  1024                // VAR 1: queue entries per workgroup (KB_C_QCAP / 8 per wave)
+#define KB_C_QCAP  (128 * (KB_C_THREADS / 64))                // VAR 1: queue entries per workgroup (128 per wave)
 #define KB_C_QEXTRA(VAR, KW) ((VAR) ? (KB_C_QCAP * ((KW) == 2 ? 18 : 10) + 16 + (KB_C_RUNS + 4) * 4) : 0)   // LDS bytes VAR 1 adds
 template <int KW, int MODE, int VAR>
-__global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
+__global__ __launch_bounds__(KB_C_THREADS) __attribute__((amdgpu_waves_per_eu(KB_C_WPE, KB_C_WPE))) void kb_bucket_kernel(
     KbPlan plan, KbScratch s, KdfTable t, KdfCtl *ctl, int table_nonempty)
 {
     constexpr int CHUNK = KbCfg<KW>::CHUNK;
@@ -606,7 +625,7 @@ __global__ __launch_bounds__(KB_C_THREADS) void kb_bucket_kernel(
         }
         __syncthreads();
         const uint32_t nruns = (uint32_t)((j1 - jb) < (unsigned long long)KB_C_RUNS ? (j1 - jb) : (unsigned long long)KB_C_RUNS);
-        constexpr int EPB = VAR >= 1 ? (KW == 2 ? 12 : 20) : 16;    // entries per thread per batch: EPB (x KW) loads in flight per lane
+        constexpr int EPB = VAR >= 1 ? (KW == 2 ? KB_C_EPB_W : KB_C_EPB_N) : 12;    // entries per thread per batch: EPB (x KW) loads in flight per lane
         // (ei * inv_total) >> 32 ~= ei * nruns / total
         const unsigned long long inv_total = total ? (((unsigned long long)nruns << 32) / total) : 0;
         for (uint32_t e0 = 0; e0 < total; e0 += KB_C_THREADS * EPB) {   // wave-uniform trip count
