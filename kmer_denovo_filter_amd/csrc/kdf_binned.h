@@ -52,6 +52,8 @@ static_assert(KB_C_THREADS % 256 == 0 && KB_C_THREADS <= 1024, "whole waves on e
 
 template <int KW> struct KbCfg;
 template <> struct KbCfg<1> { static constexpr int WPT = 16, CHUNK = 16384; };   // 8-byte entries: 128 KB of LDS
+// (WPT = 8 for narrow keys -- 8 K slabs, two workgroups per CU at 8 waves per SIMD -- was measured at 8.6 ms for A1
+// against 4.6: the runs halve and 64 VGPRs spill.)
 template <> struct KbCfg<2> { static constexpr int WPT = 8,  CHUNK = 8192;  };   // 16-byte entries
 // Wide entries travel as 16-byte (lo, hi) structs: one dwordx4 / ds_*_b128 per entry instead
 // of two 8-byte accesses to two arrays (runs are short: 9 entries in A1, 16 in C).
@@ -292,8 +294,9 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
     }
     __syncthreads();
     const uint64_t slab0 = (uint64_t)blockIdx.x * slabs_per_wg;
-    const int half = threadIdx.x >> 5, lane32 = threadIdx.x & 31;
-    constexpr int NHALF = KB_THREADS / 32;
+    constexpr int GL = 2 * WPT;                                         // lanes that copy one bin's run = its mean length (wide keys: 16 lanes instead of 32 took A1 from 8.9 to 7.9 ms)
+    const int half = threadIdx.x / GL, lane32 = threadIdx.x % GL;
+    constexpr int NHALF = KB_THREADS / GL;
     // Four barriers per slab (a 16-wave workgroup alone on its CU pays the skew of
     // its slowest wave at every barrier): rank | scan by ONE wave | LDS scatter |
     // copy-out + cursor update.  The next slab's input words are fetched before
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
             if (g + n > gend[bin]) {           // the stream changed between the passes: never write past the range
                 if (lane32 == 0 && n) s.failed_flag[0] = 1;
             } else {
-                for (uint32_t i = lane32; i < n; i += 32) {
+                for (uint32_t i = lane32; i < n; i += GL) {
                     if constexpr (KW == 2) ent2[g + i] = s2[o + i];
                     else s.ent_lo[g + i] = slo[o + i];
                 }
