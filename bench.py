@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--genome", type=int, default=100_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=10_000_000)
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N > 1 ranks on ONE GPU: gloo with host-staged collectives instead of RCCL "
                          "(checks the multi-GPU job end to end on a 1-GPU box; its timing means nothing)")
@@ -247,6 +247,8 @@ def main():
                       "count + `dump -L 3` tally, keys dealt to one partition per thread (CPU restatement, "
                       "not Jellyfish)",
         }
+        if len(offs) - 1 == args.reads:         # the whole batch was counted on the CPU: its tally must be the GPU's
+            out["cpu_baseline"]["equals_gpu_result"] = bool(cd == distinct and cg == n_ge3 and ct == windows)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
