@@ -33,7 +33,9 @@
 // the bench pass: 512 threads x 20 entries (4 waves per SIMD) 6.16 ms, 768 x 12 5.4 ms, 1024 x 8 (8 per SIMD,
 // spills) 6.0 ms; thread counts whose waves do not divide evenly over the four SIMDs (640, 896) leave one
 // workgroup per CU (9-10 ms).  12 x 768 = 9216 entries per batch also covers the bench's ~8.9 K entries per
-// bucket in one batch with 11.6 of the 12 waves busy.
+// bucket in one batch with 11.6 of the 12 waves busy.  Past six waves nothing more comes: with two keys resolved
+// together instead of four the kernel fits 64 VGPRs without spilling, and 1024 threads x 10 or 12 entries at 8 waves
+// per SIMD then take 5.7-5.8 ms; lookahead 1 / 3 instead of 2: 5.9 / 5.4-5.5 ms.
 #ifndef KB_C_THREADS
 #define KB_C_THREADS 768
 #endif
