@@ -567,7 +567,11 @@ __global__ __launch_bounds__(KB_C_THREADS) __attribute__((amdgpu_waves_per_eu(KB
     // `plan` describes the table the partition was built for.  In MODE_REPLAY
     // that is the OLD geometry (the host has grown the table since) and `t` is
     // the new table.
-    const uint64_t bucket = blockIdx.x;                       // table bucket of `plan`
+    // Workgroups are dealt to the 8 XCDs round robin by blockIdx, and each XCD has its own L2.  Neighbouring buckets
+    // (f, f + 1 of one coarse bin) read neighbouring runs of the same chunks -- they share the cache line at every run
+    // boundary and the lines of the offset table -- so an XCD takes a contiguous eighth of the buckets, in order.
+    const uint32_t nbk = gridDim.x;
+    const uint64_t bucket = (nbk & 7) ? blockIdx.x : (uint64_t)(blockIdx.x & 7) * (nbk >> 3) + (blockIdx.x >> 3);   // table bucket of `plan`
     const uint64_t pb = bucket >> plan.sub_bits;              // partition bucket holding its entries
     const uint32_t c = (uint32_t)(pb >> plan.c2), f = (uint32_t)(pb & ((1u << plan.c2) - 1));
     if constexpr (MODE == KB_MODE_REPLAY) {
