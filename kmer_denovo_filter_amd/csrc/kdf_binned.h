@@ -587,10 +587,12 @@ __global__ __launch_bounds__(KB_C_THREADS) __attribute__((amdgpu_waves_per_eu(KB
                 tcnt[i] = t.cnt[slot0 + i];
             }
         } else {
-            for (uint32_t i = threadIdx.x; i < B; i += KB_C_THREADS) {
-                tlo[i] = KDF_EMPTY;
-                if constexpr (KW == 2) thi[i] = KDF_EMPTY;
-                tcnt[i] = 0;
+            // two slots per lane and step: 16-byte LDS writes (B is even, the arrays are 16-byte aligned)
+            const ulonglong2 e2 = {KDF_EMPTY, KDF_EMPTY};
+            for (uint32_t i = threadIdx.x; i < B / 2; i += KB_C_THREADS) {
+                ((ulonglong2 *)tlo)[i] = e2;
+                if constexpr (KW == 2) ((ulonglong2 *)thi)[i] = e2;
+                ((uint2 *)tcnt)[i] = uint2{0u, 0u};
             }
         }
     }
@@ -963,14 +965,20 @@ __global__ __launch_bounds__(KB_C_THREADS) __attribute__((amdgpu_waves_per_eu(KB
     // LDS counts were advanced with plain (wrapping, non-returning) adds.  A pass
     // adds fewer than 2^32 to a slot, so a slot wrapped iff its new value is below
     // the value it had in HBM: saturate those (Jellyfish's 4-byte counter).
-    for (uint32_t i = threadIdx.x; i < B; i += KB_C_THREADS) {
+    // two slots per lane and step: 16-byte LDS reads and HBM stores for the keys, 8-byte ones for the counts
+    // (slot0 is a multiple of B, B is even: everything stays aligned)
+    for (uint32_t i = threadIdx.x; i < B / 2; i += KB_C_THREADS) {
         if constexpr (MODE == KB_MODE_INSERT) {
-            t.lo[slot0 + i] = tlo[i];
-            if constexpr (KW == 2) t.hi[slot0 + i] = thi[i];
+            ((ulonglong2 *)(t.lo + slot0))[i] = ((const ulonglong2 *)tlo)[i];
+            if constexpr (KW == 2) ((ulonglong2 *)(t.hi + slot0))[i] = ((const ulonglong2 *)thi)[i];
         }
-        uint32_t c = tcnt[i];
-        if (table_nonempty && c < t.cnt[slot0 + i]) c = 0xFFFFFFFFu;
-        t.cnt[slot0 + i] = c;
+        uint2 c = ((const uint2 *)tcnt)[i];
+        if (table_nonempty) {
+            const uint2 o = ((const uint2 *)(t.cnt + slot0))[i];
+            if (c.x < o.x) c.x = 0xFFFFFFFFu;
+            if (c.y < o.y) c.y = 0xFFFFFFFFu;
+        }
+        ((uint2 *)(t.cnt + slot0))[i] = c;
     }
     if (threadIdx.x == 0 && sh_claimed)
         atomicAdd(&ctl->distinct[(bucket % KDF_SHARDS) * 16], (unsigned long long)sh_claimed);
