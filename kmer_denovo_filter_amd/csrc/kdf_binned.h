@@ -45,11 +45,18 @@
 #ifndef KB_C_EPB_W
 #define KB_C_EPB_W 8                     // VAR 1, wide keys (4 measured the same, 12 spills)
 #endif
+#ifndef KB_C_THREADS_W
+#define KB_C_THREADS_W 512                // wide keys: 2048-slot buckets hold ~3 K entries; 512 x 8 covers them and three workgroups fit a CU
+#endif
+#ifndef KB_C_WQ_W
+#define KB_C_WQ_W 48                      // wide keys: queue entries per wave (18 B each)
+#endif
 #ifndef KB_C_WPE
 #define KB_C_WPE 6                       // waves per SIMD the register allocation aims at
 #endif
 static_assert(KB_C_EPB_N % 4 == 0 && KB_C_EPB_W % 4 == 0, "kernel C resolves entries four at a time");
-static_assert(KB_C_THREADS % 256 == 0 && KB_C_THREADS <= 1024, "whole waves on every SIMD");
+static_assert(KB_C_THREADS % 256 == 0 && KB_C_THREADS <= 1024 && KB_C_THREADS_W % 256 == 0 && KB_C_THREADS_W <= KB_C_THREADS, "whole waves on every SIMD");
+#define KB_C_CT(KW) ((KW) == 2 ? KB_C_THREADS_W : KB_C_THREADS)
 #define KB_C_RUNS    256                 // runs (chunks of the coarse bin) staged per round
 
 template <int KW> struct KbCfg;
@@ -542,13 +549,14 @@ __device__ __forceinline__ void kb_probe_wide_wave(uint64_t *tlo, uint64_t *thi,
 // barrier) and are probed densely, one per lane, after the batch.  Measured on the
 // bench pass: kernel C 7.6 -> 6.5 ms at k = 31, 16.0 -> 12.7 ms at k = 63.
 #define KB_C_LA    2                   // VAR 1: slots of the probe sequence read up front
-#define KB_C_QCAP  (128 * (KB_C_THREADS / 64))                // VAR 1: queue entries per workgroup (128 per wave)
-#define KB_C_QEXTRA(VAR, KW) ((VAR) ? (KB_C_QCAP * ((KW) == 2 ? 18 : 10) + 16 + (KB_C_RUNS + 4) * 4) : 0)   // LDS bytes VAR 1 adds
+#define KB_C_QCAPK(KW) (((KW) == 2 ? KB_C_WQ_W : 128) * (KB_C_CT(KW) / 64))   // VAR 1: queue entries per workgroup
+#define KB_C_QEXTRA(VAR, KW) ((VAR) ? (KB_C_QCAPK(KW) * ((KW) == 2 ? 18 : 10) + 16 + (KB_C_RUNS + 4) * 4) : 0)   // LDS bytes VAR 1 adds
 template <int KW, int MODE, int VAR>
-__global__ __launch_bounds__(KB_C_THREADS) __attribute__((amdgpu_waves_per_eu(KB_C_WPE, KB_C_WPE))) void kb_bucket_kernel(
+__global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_C_WPE, KB_C_WPE))) void kb_bucket_kernel(
     KbPlan plan, KbScratch s, KdfTable t, KdfCtl *ctl, int table_nonempty)
 {
     constexpr int CHUNK = KbCfg<KW>::CHUNK;
+    constexpr uint32_t CT = KB_C_CT(KW), QCAP = KB_C_QCAPK(KW);      // threads and queue entries per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t B = 1u << plan.bucket_bits;
     uint64_t *tlo = (uint64_t *)smem;                         // [B]
@@ -559,10 +567,10 @@ __global__ __launch_bounds__(KB_C_THREADS) __attribute__((amdgpu_waves_per_eu(KB
     uint32_t *run_pref = wsum + 32;                           // [KB_C_RUNS] exclusive prefix of run lengths
     unsigned long long *run_first = (unsigned long long *)(run_pref + KB_C_RUNS);   // [KB_C_RUNS] (B + 34 + KB_C_RUNS is even: 8-aligned)
     uint32_t *run_hi = (uint32_t *)(run_first + KB_C_RUNS);   // [KB_C_RUNS] wide keys only: distance (words) from a run's lo words to its hi words
-    uint64_t *qk = (uint64_t *)(run_hi + (KW == 2 ? KB_C_RUNS : 0));   // [KB_C_QCAP] VAR 1: keys whose probe goes past the lookahead (per wave: KB_C_QCAP / 8)
-    uint16_t *qs = (uint16_t *)(qk + KB_C_QCAP);              // [KB_C_QCAP] slot to go on from
-    uint64_t *qk2 = (uint64_t *)((uint32_t *)(qs + KB_C_QCAP) + 2 + KB_C_RUNS + 4);   // [KB_C_QCAP] wide keys: hi words of the queued keys
-    uint32_t *rpw = (uint32_t *)(qs + KB_C_QCAP) + 2;                                  // [KB_C_RUNS + 4] VAR >= 1: run_pref shifted by one, padded with `total`
+    uint64_t *qk = (uint64_t *)(run_hi + (KW == 2 ? KB_C_RUNS : 0));   // [QCAP] VAR 1: keys whose probe goes past the lookahead (per wave: QCAP / 8)
+    uint16_t *qs = (uint16_t *)(qk + QCAP);              // [QCAP] slot to go on from
+    uint64_t *qk2 = (uint64_t *)((uint32_t *)(qs + QCAP) + 2 + KB_C_RUNS + 4);   // [QCAP] wide keys: hi words of the queued keys
+    uint32_t *rpw = (uint32_t *)(qs + QCAP) + 2;                                  // [KB_C_RUNS + 4] VAR >= 1: run_pref shifted by one, padded with `total`
 
     // `plan` describes the table the partition was built for.  In MODE_REPLAY
     // that is the OLD geometry (the host has grown the table since) and `t` is
@@ -581,7 +589,7 @@ __global__ __launch_bounds__(KB_C_THREADS) __attribute__((amdgpu_waves_per_eu(KB
     if (threadIdx.x == 0) { sh_failed = 0; sh_claimed = 0; }
     if constexpr (MODE != KB_MODE_REPLAY) {
         if (table_nonempty) {
-            for (uint32_t i = threadIdx.x; i < B; i += KB_C_THREADS) {
+            for (uint32_t i = threadIdx.x; i < B; i += CT) {
                 tlo[i] = t.lo[slot0 + i];
                 if constexpr (KW == 2) thi[i] = t.hi[slot0 + i];
                 tcnt[i] = t.cnt[slot0 + i];
@@ -589,7 +597,7 @@ __global__ __launch_bounds__(KB_C_THREADS) __attribute__((amdgpu_waves_per_eu(KB
         } else {
             // two slots per lane and step: 16-byte LDS writes (B is even, the arrays are 16-byte aligned)
             const ulonglong2 e2 = {KDF_EMPTY, KDF_EMPTY};
-            for (uint32_t i = threadIdx.x; i < B / 2; i += KB_C_THREADS) {
+            for (uint32_t i = threadIdx.x; i < B / 2; i += CT) {
                 ((ulonglong2 *)tlo)[i] = e2;
                 if constexpr (KW == 2) ((ulonglong2 *)thi)[i] = e2;
                 ((uint2 *)tcnt)[i] = uint2{0u, 0u};
@@ -598,7 +606,7 @@ __global__ __launch_bounds__(KB_C_THREADS) __attribute__((amdgpu_waves_per_eu(KB
     }
     __syncthreads();
 
-    constexpr uint32_t WQ = KB_C_QCAP / (KB_C_THREADS / 64);
+    constexpr uint32_t WQ = QCAP / (CT / 64);
     uint64_t *wqk = qk + (threadIdx.x >> 6) * WQ;
     uint64_t *wqk2 = qk2 + (threadIdx.x >> 6) * WQ;
     uint16_t *wqs = qs + (threadIdx.x >> 6) * WQ;
@@ -639,7 +647,7 @@ __global__ __launch_bounds__(KB_C_THREADS) __attribute__((amdgpu_waves_per_eu(KB
         constexpr int EPB = VAR >= 1 ? (KW == 2 ? KB_C_EPB_W : KB_C_EPB_N) : 12;    // entries per thread per batch: EPB (x KW) loads in flight per lane
         // (ei * inv_total) >> 32 ~= ei * nruns / total
         const unsigned long long inv_total = total ? (((unsigned long long)nruns << 32) / total) : 0;
-        for (uint32_t e0 = 0; e0 < total; e0 += KB_C_THREADS * EPB) {   // wave-uniform trip count
+        for (uint32_t e0 = 0; e0 < total; e0 += CT * EPB) {   // wave-uniform trip count
           uint64_t bklo[EPB], bkhi[KW == 2 ? EPB : 1];
           // Flat index of this thread's q-th entry of the batch.  Narrow keys (VAR 1): a WAVE takes 64 * EPB
           // consecutive entries, lane l's q-th entry is wbase + 64 q -- one load instruction still reads 64
@@ -649,7 +657,7 @@ __global__ __launch_bounds__(KB_C_THREADS) __attribute__((amdgpu_waves_per_eu(KB
           // Wide keys have 16-entry runs (four runs per step): they keep the per-entry windowed search.
           constexpr bool WAVE_SPANS = VAR >= 1 && KW == 1;
           const uint32_t wbase = WAVE_SPANS ? e0 + (threadIdx.x >> 6) * (64 * EPB) + (threadIdx.x & 63) : e0 + threadIdx.x;
-          constexpr uint32_t QSTEP = WAVE_SPANS ? 64u : (uint32_t)KB_C_THREADS;      // flat-index distance between a thread's consecutive entries
+          constexpr uint32_t QSTEP = WAVE_SPANS ? 64u : (uint32_t)CT;      // flat-index distance between a thread's consecutive entries
           if constexpr (WAVE_SPANS) {
             uint32_t cr = 0, cpf = 0, cnx = 0;                 // current run: index, first flat entry, first entry of the next run
             if (wbase < total) {
@@ -687,7 +695,7 @@ __global__ __launch_bounds__(KB_C_THREADS) __attribute__((amdgpu_waves_per_eu(KB
             // round trips per four entries instead of a dependent probe chain per entry
 #pragma unroll
             for (int q0 = 0; q0 < EPB; q0 += 4) {
-                if (e0 + q0 * KB_C_THREADS >= total) {
+                if (e0 + q0 * CT >= total) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) { bklo[q0 + g] = 0; if constexpr (KW == 2) bkhi[q0 + g] = 0; }
                     continue;
@@ -739,7 +747,7 @@ __global__ __launch_bounds__(KB_C_THREADS) __attribute__((amdgpu_waves_per_eu(KB
           } else {
 #pragma unroll
           for (int q = 0; q < EPB; ++q) {
-            const uint32_t ei = e0 + q * KB_C_THREADS + threadIdx.x;
+            const uint32_t ei = e0 + q * CT + threadIdx.x;
             bklo[q] = 0; if constexpr (KW == 2) bkhi[q] = 0;
             if (ei < total) {
                 // largest r with run_pref[r] <= ei.  Runs of a bucket have nearly equal
@@ -830,7 +838,7 @@ __global__ __launch_bounds__(KB_C_THREADS) __attribute__((amdgpu_waves_per_eu(KB
             constexpr int G = 2;
 #pragma unroll
             for (int q0 = 0; q0 < EPB; q0 += G) {
-                if (e0 + q0 * KB_C_THREADS >= total) break;
+                if (e0 + q0 * CT >= total) break;
                 uint64_t chi[G][KB_C_LA], clo[G][KB_C_LA]; uint32_t sl0[G]; bool td[G];
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
@@ -906,7 +914,7 @@ __global__ __launch_bounds__(KB_C_THREADS) __attribute__((amdgpu_waves_per_eu(KB
           } else {
 #pragma unroll
           for (int q = 0; q < EPB; ++q) {
-            const uint32_t ei = e0 + q * KB_C_THREADS + threadIdx.x;
+            const uint32_t ei = e0 + q * CT + threadIdx.x;
             bool todo = ei < total;
             const uint64_t klo = bklo[q], khi = KW == 2 ? bkhi[q] : 0;
             const uint64_t h = kdf_hash(klo, khi);
@@ -953,7 +961,7 @@ __global__ __launch_bounds__(KB_C_THREADS) __attribute__((amdgpu_waves_per_eu(KB
             atomicAdd(&s.totals[2], 1ull);
         }
         if (!table_nonempty) {
-            for (uint32_t i = threadIdx.x; i < B; i += KB_C_THREADS) {
+            for (uint32_t i = threadIdx.x; i < B; i += CT) {
                 t.lo[slot0 + i] = KDF_EMPTY;
                 if constexpr (KW == 2) t.hi[slot0 + i] = KDF_EMPTY;
                 t.cnt[slot0 + i] = 0;
@@ -967,7 +975,7 @@ __global__ __launch_bounds__(KB_C_THREADS) __attribute__((amdgpu_waves_per_eu(KB
     // the value it had in HBM: saturate those (Jellyfish's 4-byte counter).
     // two slots per lane and step: 16-byte LDS reads and HBM stores for the keys, 8-byte ones for the counts
     // (slot0 is a multiple of B, B is even: everything stays aligned)
-    for (uint32_t i = threadIdx.x; i < B / 2; i += KB_C_THREADS) {
+    for (uint32_t i = threadIdx.x; i < B / 2; i += CT) {
         if constexpr (MODE == KB_MODE_INSERT) {
             ((ulonglong2 *)(t.lo + slot0))[i] = ((const ulonglong2 *)tlo)[i];
             if constexpr (KW == 2) ((ulonglong2 *)(t.hi + slot0))[i] = ((const ulonglong2 *)thi)[i];

@@ -595,13 +595,13 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     const bool var1 = !(h->opt_debug_flags & 8);
     const int nonempty = h->lazy_empty ? 0 : 1;   // 0: kernel C rewrites every bucket (this IS the clear)
     if (filtered)
-#define KB_LV(M, V) hipLaunchKernelGGL((kb_bucket_kernel<KW, M, V>), dim3((unsigned)nb_table), dim3(KB_C_THREADS), lds_c + KB_C_QEXTRA(V, KW), h->stream, plan, s, h->t, h->ctl, nonempty)
+#define KB_LV(M, V) hipLaunchKernelGGL((kb_bucket_kernel<KW, M, V>), dim3((unsigned)nb_table), dim3(KB_C_CT(KW)), lds_c + KB_C_QEXTRA(V, KW), h->stream, plan, s, h->t, h->ctl, nonempty)
 #define KB_LVS(M) KB_LV(M, 1)
         if (var1) KB_LVS(KB_MODE_FILTERED);
-        else hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_FILTERED, 0>), dim3((unsigned)nb_table), dim3(KB_C_THREADS), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty);
+        else hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_FILTERED, 0>), dim3((unsigned)nb_table), dim3(KB_C_CT(KW)), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty);
     else
         if (var1) KB_LVS(KB_MODE_INSERT);
-        else hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_INSERT, 0>), dim3((unsigned)nb_table), dim3(KB_C_THREADS), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty);
+        else hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_INSERT, 0>), dim3((unsigned)nb_table), dim3(KB_C_CT(KW)), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty);
     HIPCHK(h, hipGetLastError());
     if (h->prof) {
         stamp();                                               // end of C
@@ -629,7 +629,7 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     const uint64_t worst = h->distinct + std::min<uint64_t>(n_entries, n_failed * ((n_entries / std::max<uint64_t>(nb_table, 1)) * 4 + 4096));
     uint32_t want = std::max<uint32_t>(h->t.log2cap + 1, cap_log2_for(worst));
     if ((rc = table_rehash(h, want))) return rc;
-    hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_REPLAY, 0>), dim3((unsigned)nb_table), dim3(KB_C_THREADS), lds_c, h->stream, plan, s, h->t, h->ctl, 1);
+    hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_REPLAY, 0>), dim3((unsigned)nb_table), dim3(KB_C_CT(KW)), lds_c, h->stream, plan, s, h->t, h->ctl, 1);
     HIPCHK(h, hipGetLastError());
     if ((rc = ctl_sync(h, &full))) return rc;
     if (full) return fail(h, KDF_ERR_TABLE_FULL, "binned count: bucket overflow during replay (capacity 2^%u)", h->t.log2cap);
