@@ -79,14 +79,18 @@ int kdf_stats(kdf_engine *h, uint64_t *capacity, uint64_t *distinct, uint64_t *w
 
 /* Tuning knobs and counters (tests force either kernel path through these):
  *   options  "force_path" 0 auto / 1 direct global-table kernels / 2 binned
- *            LDS-bucket pipeline; "binned_min_positions" (stream positions from
+ *            LDS-bucket pipeline / 3 super-k-mer pipeline (minimizer-bucketed table, 16 <= k <= 32;
+ *            chosen on an EMPTY table, which then keeps that layout until kdf_clear); "sk_min_k" (auto:
+ *            smallest k that takes the super-k-mer pipeline); "binned_min_positions" (stream positions from
  *            which count calls take the binned path); "key_parts" / "key_part" (count only
  *            the windows whose key lies in slice key_part of key_parts of the key space --
  *            ranges of the LOW 16 hash bits, so a slice spreads over the whole table -- so that
  *            a sample whose distinct k-mers exceed one table is counted slice by slice over
  *            the same stream; insert mode only; 0/1 = everything); "binned_max_positions" (positions per
  *            binned pass, <= 2^31: longer streams take several passes); "binned_filtered_min_log2cap"
- *   stats    "binned_passes", "replayed_buckets", "log2cap", "bucket_bits" */
+ *   stats    "binned_passes", "replayed_buckets", "log2cap", "bucket_bits", "layout" (1 = minimizer-bucketed),
+ *            "last_count_path" (0 direct / 1 binned / 2 super-k-mer), "sk_passes", "sk_spills",
+ *            "sk_failed_buckets", "sk_fallbacks", "ovf_log2cap" */
 int kdf_set_option(kdf_engine *h, const char *name, int64_t value);
 /* Free / total HBM of a device (hipMemGetInfo): the child-count mirror sizes "key_parts" with it. */
 int kdf_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
@@ -133,6 +137,13 @@ int kdf_add_pairs_dev(kdf_engine *h, const void *d_keys_lo, const void *d_keys_h
  * must already be canonical (the reference's filter files are). */
 int kdf_load_filter(kdf_engine *h, const uint64_t *keys_lo, const uint64_t *keys_hi,
                     uint64_t n);
+/* The same with the keys already resident in HBM (device pointers): the hand-off between the discovery stages
+ * (child candidates -> reference subtraction -> parent filter, discovery/pipeline.py:207-226,286-304,515-532)
+ * without a host round trip. */
+int kdf_load_filter_dev(kdf_engine *h, const void *d_keys_lo, const void *d_keys_hi, uint64_t n);
+/* Zero every count, keep the keys (and the filter mode): the same filter counted against the next parent
+ * (discovery/pipeline.py:462-612 builds a fresh --if table per parent). */
+int kdf_reset_counts(kdf_engine *h);
 /* `jellyfish count -C --if`: only windows whose canonical k-mer is in the table
  * are counted; nothing is inserted.  Replaces _scan_parent_jellyfish
  * (core/jellyfish_wrappers.py:115-283) and _count_parent_jellyfish
@@ -166,9 +177,11 @@ int kdf_export_ge(kdf_engine *h, uint32_t min_count, uint64_t *keys_lo_out,
                   uint64_t *n_out);
 
 /* Device-to-device dump: the entries go to caller-owned HBM buffers (e.g. torch
- * tensors that are then exchanged over RCCL); unsorted unless sorted != 0.
- * d_keys_hi_out may be NULL for k <= 32, d_counts_out may be NULL when
- * sorted == 0.  Synchronises the engine's stream before returning. */
+ * tensors that are then exchanged over RCCL, or the next stage's filter); unsorted
+ * unless sorted != 0.  ONE pass over the table: at most `cap` entries are written,
+ * *n_out is the number the dump holds; KDF_ERR_INVALID when that exceeds cap
+ * (kdf_count_ge sizes the buffers).  d_keys_hi_out may be NULL for k <= 32,
+ * d_counts_out may be NULL when sorted == 0.  Synchronises the engine's stream. */
 int kdf_export_ge_dev(kdf_engine *h, uint32_t min_count, void *d_keys_lo_out,
                       void *d_keys_hi_out, void *d_counts_out, uint64_t cap,
                       int sorted, uint64_t *n_out);

@@ -37,6 +37,8 @@ SYMBOLS = [
     ("kdf_add_pairs", c_int, [_P, _P, _P, _P, c_uint64]),
     ("kdf_add_pairs_dev", c_int, [_P, _P, _P, _P, c_uint64]),
     ("kdf_load_filter", c_int, [_P, _P, _P, c_uint64]),
+    ("kdf_load_filter_dev", c_int, [_P, _P, _P, c_uint64]),
+    ("kdf_reset_counts", c_int, [_P]),
     ("kdf_count_reads_filtered", c_int, [_P, _P, _P, c_uint64]),
     ("kdf_count_reads_filtered_dev", c_int, [_P, _P, _P, c_uint64]),
     ("kdf_query", c_int, [_P, _P, _P, c_uint64, _P]),

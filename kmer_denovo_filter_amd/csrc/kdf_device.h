@@ -57,6 +57,17 @@ struct KdfTable {
     // one table is counted in several passes over the same stream.
     uint32_t key_parts;    // 0 or 1: everything
     uint32_t key_part;
+    // Minimizer-bucketed ("SK") layout, narrow keys only (kdf_sk.h): the BUCKET of a key is chosen by its minimizer
+    // (smallest canonical 12-mer under sk_order), so all k-mers of a minimizer-delimited read substring share a
+    // bucket; the slot inside the bucket still comes from the key's hash.  A key whose probe sequence finds neither
+    // itself nor an empty slot within KDF_SK_MAXPROBE slots lives in the overflow table (plain open addressing over
+    // the whole ovf array), so a minimizer that owns more distinct k-mers than a bucket holds is never an error.
+    uint32_t sk;           // 0: hash layout (bucket = top hash bits)
+    uint32_t k;            // k-mer length (SK lookups derive the minimizer from the key)
+    uint64_t *ovf_lo;
+    uint32_t *ovf_cnt;
+    uint32_t ovf_log2cap;
+    uint32_t pad_;
 };
 
 // Slice of a key from the LOW 16 bits of its hash.  (The multi-GPU owner function uses the TOP bits, which are
@@ -77,6 +88,39 @@ struct KdfCtl {            // device-resident control block (one per engine)
 
 __device__ __forceinline__ uint64_t kdf_home(const KdfTable &t, uint64_t h) {
     return h >> (64 - t.log2cap);
+}
+
+// ---- minimizer-bucketed layout ------------------------------------------------
+#define KDF_SK_M        12                  // minimizer length: 24-bit canonical m-mers
+#define KDF_SK_MAXPROBE 64u                 // slots of a bucket a probe may visit before it turns to the overflow table
+// ORDER of the minimizer scheme: an injective 24-bit scramble (odd multiply mod 2^24, xor-shift) of the canonical
+// m-mer code.  Its top bits name the bucket, so they must be well mixed; one full-rate v_mul_u32_u24.
+__host__ __device__ __forceinline__ uint32_t kdf_sk_order(uint32_t cm) {
+    uint32_t g = (cm * 0x9E3779u) & 0xFFFFFFu;
+    return g ^ (g >> 11);
+}
+// minimizer order value of a canonical k-mer x (MSB-first code), k >= KDF_SK_M
+__host__ __device__ __forceinline__ uint32_t kdf_sk_min_of_key(uint64_t x, int k) {
+    constexpr uint32_t MM = (1u << (2 * KDF_SK_M)) - 1;
+    const uint64_t y = kdf_rev2(~x) >> (64 - 2 * k);           // reverse complement of x
+    uint32_t g = 0xFFFFFFFFu;
+    for (int j = 0; j <= k - KDF_SK_M; ++j) {
+        const uint32_t fw = (uint32_t)(x >> (2 * (k - KDF_SK_M - j))) & MM;    // m-mer at offset j
+        const uint32_t rc = (uint32_t)(y >> (2 * j)) & MM;                      // its reverse complement
+        const uint32_t o = kdf_sk_order(fw < rc ? fw : rc);
+        g = o < g ? o : g;
+    }
+    return g;
+}
+// bucket of an order value: its top bits (nb_bits = log2cap - bucket_bits <= 24)
+__host__ __device__ __forceinline__ uint32_t kdf_sk_bucket_of(uint32_t g, uint32_t nb_bits) {
+    return nb_bits ? (g >> (24 - nb_bits)) : 0u;
+}
+// first slot of key's probe sequence in an SK table
+__device__ __forceinline__ uint64_t kdf_sk_home(const KdfTable &t, uint64_t key) {
+    const uint32_t nb_bits = t.log2cap - t.bucket_bits;
+    const uint64_t b = kdf_sk_bucket_of(kdf_sk_min_of_key(key, (int)t.k), nb_bits);
+    return (b << t.bucket_bits) | (kdf_mix64(key) >> (64 - t.bucket_bits));
 }
 
 __device__ __forceinline__ void kdf_sat_add(uint32_t *p, uint32_t add) {
@@ -107,6 +151,68 @@ __device__ __forceinline__ bool kdf_add_narrow(const KdfTable &t, uint64_t key, 
         slot = base | ((slot + 1) & bmask);
         cur = t.lo[slot];
     }
+}
+
+// SK layout, one key through global memory (index loads, merges, rehash).  kdf_sk_main_add tries the key's bucket
+// neighbourhood and returns false when it holds neither the key nor an empty slot: the key then belongs to the
+// overflow table (kdf_sk_ovf_add; false there = the overflow table is full, the host sizes it so that cannot happen).
+template <bool INSERT>
+__device__ __forceinline__ bool kdf_sk_main_add(const KdfTable &t, uint64_t key, uint32_t add, uint32_t &claimed) {
+    const uint64_t bmask = (1ull << t.bucket_bits) - 1;
+    uint64_t slot = kdf_sk_home(t, key);
+    const uint64_t base = slot & ~bmask;
+    const uint64_t lim = bmask + 1 < KDF_SK_MAXPROBE ? bmask + 1 : KDF_SK_MAXPROBE;
+    for (uint64_t i = 0; i < lim; ++i) {
+        uint64_t cur = t.lo[slot];
+        if (cur == KDF_EMPTY) {
+            if (!INSERT) return true;
+            cur = atomicCAS((unsigned long long *)&t.lo[slot], KDF_EMPTY, key);
+            if (cur == KDF_EMPTY) { claimed++; cur = key; }
+        }
+        if (cur == key) { if (add) kdf_sat_add(&t.cnt[slot], add); return true; }
+        slot = base | ((slot + 1) & bmask);
+    }
+    return false;
+}
+template <bool INSERT>
+__device__ __forceinline__ bool kdf_sk_ovf_add(const KdfTable &t, uint64_t key, uint32_t add, uint32_t &claimed) {
+    if (!t.ovf_lo) return false;
+    const uint64_t omask = (1ull << t.ovf_log2cap) - 1;
+    uint64_t os = kdf_mix64(key) >> (64 - t.ovf_log2cap);
+    for (uint64_t i = 0; i <= omask; ++i) {
+        uint64_t cur = t.ovf_lo[os];
+        if (cur == KDF_EMPTY) {
+            if (!INSERT) return true;
+            cur = atomicCAS((unsigned long long *)&t.ovf_lo[os], KDF_EMPTY, key);
+            if (cur == KDF_EMPTY) { claimed++; cur = key; }
+        }
+        if (cur == key) { if (add) kdf_sat_add(&t.ovf_cnt[os], add); return true; }
+        os = (os + 1) & omask;
+    }
+    return false;
+}
+// count of key in an SK table (0 when absent)
+__device__ __forceinline__ uint32_t kdf_count_sk(const KdfTable &t, uint64_t key) {
+    const uint64_t bmask = (1ull << t.bucket_bits) - 1;
+    uint64_t slot = kdf_sk_home(t, key);
+    const uint64_t base = slot & ~bmask;
+    const uint64_t lim = bmask + 1 < KDF_SK_MAXPROBE ? bmask + 1 : KDF_SK_MAXPROBE;
+    for (uint64_t i = 0; i < lim; ++i) {
+        const uint64_t cur = t.lo[slot];
+        if (cur == key) return t.cnt[slot];
+        if (cur == KDF_EMPTY) return 0u;
+        slot = base | ((slot + 1) & bmask);
+    }
+    if (!t.ovf_lo) return 0u;
+    const uint64_t omask = (1ull << t.ovf_log2cap) - 1;
+    uint64_t os = kdf_mix64(key) >> (64 - t.ovf_log2cap);
+    for (uint64_t i = 0; i <= omask; ++i) {
+        const uint64_t cur = t.ovf_lo[os];
+        if (cur == key) return t.ovf_cnt[os];
+        if (cur == KDF_EMPTY) return 0u;
+        os = (os + 1) & omask;
+    }
+    return 0u;
 }
 
 // returns the slot of key or ~0 when absent

@@ -13,6 +13,7 @@
 #include "kdf.h"
 #include "kdf_device.h"
 #include "kdf_binned.h"
+#include "kdf_sk.h"
 
 // sorted export lives in kdf_sort.hip (rocPRIM radix sort)
 int kdf_sort_pairs_device(uint64_t *d_lo, uint64_t *d_hi, uint32_t *d_cnt, uint64_t n,
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(256) void kdf_stream_kernel(
                     const bool ok = (valid >> (b + u)) & 1;
                     if constexpr (MODE == MODE_SCAN) {
                         if (!ok) continue;
+                        if (KW == 1 && t.sk) { if (kdf_count_sk(t, klo[u]) != 0) hits |= 1ull << (b + u); continue; }
                         uint64_t s = KW == 1 ? kdf_find_narrow(t, klo[u]) : kdf_find_wide(t, klo[u], khi[u]);
                         if (s != ~0ull && t.cnt[s] != 0) hits |= 1ull << (b + u);
                     } else if constexpr (KW == 1) {
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(256) void kdf_query_kernel(
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (KW == 1 && t.sk) { out[i] = kdf_count_sk(t, klo[i]); return; }
     const uint64_t s = KW == 1 ? kdf_find_narrow(t, klo[i]) : kdf_find_wide(t, klo[i], khi[i]);
     out[i] = (s == ~0ull) ? 0u : t.cnt[s];
 }
@@ -260,7 +263,17 @@ struct kdf_engine {
     uint64_t opt_binned_max_positions = 1ull << 31;  // longer streams are walked in several binned passes: a pass must add
                                                      // < 2^32 to any slot (kernel C saturates by comparing with the HBM count)
     uint32_t opt_binned_filtered_min_log2cap = 23;   // count --if goes binned from 2^23 slots (measured crossover)
-    int opt_force_path = 0;                          // 0 auto, 1 direct, 2 binned
+    int opt_force_path = 0;                          // 0 auto, 1 direct, 2 binned, 3 super-k-mer (kdf_sk.h)
+    uint32_t opt_sk_min_k = 20;                      // auto: narrow keys from this k on take the super-k-mer path
+    // super-k-mer path (kdf_sk.h): scratch, device counters + pinned mirror, overflow table bookkeeping
+    void *sk_buf[16] = {nullptr};
+    size_t sk_bytes[16] = {0};
+    uint32_t *sk_ctrs = nullptr, *sk_ctrs_host = nullptr;
+    uint64_t ovf_used_ub = 0;                        // upper bound of the keys in the overflow table
+    bool ovf_dirty = false;                          // overflow arrays hold entries of an earlier table generation
+    bool sk_attrs_set[64] = {false};
+    uint64_t stat_sk_passes = 0, stat_sk_spills = 0, stat_sk_failed = 0, stat_sk_fallbacks = 0;
+    int last_path = 0;                               // count path of the last count call: 0 direct, 1 binned, 2 super-k-mer
     uint32_t opt_debug_flags = 0;                    // experiments only (KbPlan::dbg)
     uint64_t stat_binned_passes = 0, stat_replayed_buckets = 0;
     uint64_t stat_dbg[6] = {0, 0, 0, 0, 0, 0};        // diagnostic stamps of the last binned pass
@@ -332,6 +345,8 @@ static void table_free(KdfTable &t) {
     if (t.lo) (void)hipFree(t.lo);
     if (t.hi) (void)hipFree(t.hi);
     if (t.cnt) (void)hipFree(t.cnt);
+    if (t.ovf_lo) (void)hipFree(t.ovf_lo);
+    if (t.ovf_cnt) (void)hipFree(t.ovf_cnt);
     t = KdfTable{};
 }
 
@@ -381,8 +396,11 @@ static int ctl_reset(kdf_engine *h, bool keep_windows) {
 template <typename F>
 static int by_width(kdf_engine *h, F &&f) { return h->kw == 1 ? f(std::integral_constant<int, 1>{}) : f(std::integral_constant<int, 2>{}); }
 
+static int sk_table_rehash(kdf_engine *h, uint32_t new_log2);
+
 // rehash the live table into one with 2^new_log2 slots
 static int table_rehash(kdf_engine *h, uint32_t new_log2) {
+    if (h->t.sk) return sk_table_rehash(h, new_log2);
     { int rc0 = materialize(h); if (rc0) return rc0; }
     KdfTable nt;
     int rc = table_alloc(h, new_log2, nt);
@@ -636,6 +654,346 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     return KDF_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// super-k-mer path (kdf_sk.h)
+
+enum { SKB_CHUNKS = 0, SKB_CBIN, SKB_CPOS, SKB_CFILL, SKB_CLIST, SKB_SMALL, SKB_SORTED, SKB_GOFF, SKB_FAILED, SKB_SPKEY, SKB_SPCNT };
+#define SK_RC_EXHAUSTED (-1000)
+
+static int sk_reserve(kdf_engine *h, int i, size_t bytes) {
+    if (h->sk_bytes[i] >= bytes) return KDF_OK;
+    if (h->sk_buf[i]) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->sk_buf[i]); h->sk_buf[i] = nullptr; h->sk_bytes[i] = 0; }
+    const size_t want = bytes + bytes / 16 + 4096;
+    HIPCHK(h, hipMalloc(&h->sk_buf[i], want));
+    h->sk_bytes[i] = want;
+    return KDF_OK;
+}
+
+static int sk_ctrs_init(kdf_engine *h) {
+    if (h->sk_ctrs) return KDF_OK;
+    HIPCHK(h, hipMalloc((void **)&h->sk_ctrs, SKC_N * 4));
+    HIPCHK(h, hipHostMalloc((void **)&h->sk_ctrs_host, SKC_N * 4));
+    return KDF_OK;
+}
+
+// (re)allocate an EMPTY overflow table of 2^log2cap slots for table t
+static int ovf_alloc(kdf_engine *h, KdfTable &t, uint32_t log2cap) {
+    if (t.ovf_lo && t.ovf_log2cap != log2cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        (void)hipFree(t.ovf_lo); (void)hipFree(t.ovf_cnt); t.ovf_lo = nullptr; t.ovf_cnt = nullptr;
+    }
+    const uint64_t cap = 1ull << log2cap;
+    if (!t.ovf_lo) {
+        HIPCHK(h, hipMalloc((void **)&t.ovf_lo, cap * 8));
+        HIPCHK(h, hipMalloc((void **)&t.ovf_cnt, cap * 4));
+        t.ovf_log2cap = log2cap;
+    }
+    HIPCHK(h, hipMemsetAsync(t.ovf_lo, 0xFF, cap * 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(t.ovf_cnt, 0, cap * 4, h->stream));
+    return KDF_OK;
+}
+
+// make room for `more` further keys in the live overflow table (load <= 0.5), re-placing what it holds
+static int ovf_ensure(kdf_engine *h, uint64_t more) {
+    const uint64_t need = (h->ovf_used_ub + more) * 2;
+    if (h->t.ovf_lo && need <= (1ull << h->t.ovf_log2cap)) return KDF_OK;
+    const uint32_t nl = std::max<uint32_t>(16, log2ceil(std::max<uint64_t>(need, 1) * 2));
+    int rc;
+    if (!h->t.ovf_lo || h->ovf_used_ub == 0) { rc = ovf_alloc(h, h->t, nl); h->ovf_dirty = false; return rc; }
+    if ((rc = sk_ctrs_init(h))) return rc;
+    KdfTable nt = h->t;
+    nt.ovf_lo = nullptr; nt.ovf_cnt = nullptr;
+    if ((rc = ovf_alloc(h, nt, nl))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->sk_ctrs + 8, 0, 4, h->stream));
+    const uint64_t ocap = 1ull << h->t.ovf_log2cap;
+    hipLaunchKernelGGL(sk_ovf_rehash_kernel, dim3((unsigned)((ocap + 255) / 256)), dim3(256), 0, h->stream,
+                       (const uint64_t *)h->t.ovf_lo, (const uint32_t *)h->t.ovf_cnt, ocap, nt, h->ctl, h->sk_ctrs + 8);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(h->sk_ctrs_host + 8, h->sk_ctrs + 8, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(h->t.ovf_lo); (void)hipFree(h->t.ovf_cnt);
+    h->t.ovf_lo = nt.ovf_lo; h->t.ovf_cnt = nt.ovf_cnt; h->t.ovf_log2cap = nl;
+    h->ovf_used_ub = h->sk_ctrs_host[8];              // exact now
+    return KDF_OK;
+}
+
+static SkPlan sk_make_plan(const KdfTable &t, int k) {
+    SkPlan p{};
+    p.log2cap = t.log2cap; p.bucket_bits = t.bucket_bits; p.k = (uint32_t)k;
+    const uint32_t nb_bits = t.log2cap - t.bucket_bits;
+    p.c2 = std::min<uint32_t>(SK_C2_MAX, nb_bits);
+    p.c1 = std::min<uint32_t>(SK_C1_MAX, nb_bits - p.c2);
+    p.sub_bits = nb_bits - p.c1 - p.c2;
+    p.goff_stride = (1u << p.c2) + 1;
+    return p;
+}
+
+// the logically EMPTY table becomes minimizer-bucketed (2048-slot buckets: three bucket workgroups per CU)
+static int sk_enter(kdf_engine *h) {
+    if (h->t.sk) return KDF_OK;
+    h->t.sk = 1; h->t.k = (uint32_t)h->k;
+    h->t.bucket_bits = std::min<uint32_t>(h->t.log2cap, 11);
+    h->ovf_used_ub = 0;
+    int rc = ovf_alloc(h, h->t, h->t.ovf_lo ? h->t.ovf_log2cap : 16);
+    h->ovf_dirty = false;
+    return rc;
+}
+static void sk_leave(kdf_engine *h) {                  // back to the hash layout (the table must be logically empty)
+    if (!h->t.sk) return;
+    h->t.sk = 0;
+    h->t.bucket_bits = std::min<uint32_t>(h->t.log2cap, 12);
+    h->ovf_used_ub = 0; h->ovf_dirty = true;
+}
+
+template <int K>
+static int sk_launch_extract(kdf_engine *h, unsigned grid, size_t lds, const uint64_t *d_packed, const uint64_t *d_invalid,
+                             uint64_t n_bases, const SkPlan &plan, const SkScratch &s, uint32_t slabs_per_wg) {
+    if (!h->sk_attrs_set[K]) {
+        HIPCHK(h, hipFuncSetAttribute((const void *)sk_extract_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        h->sk_attrs_set[K] = true;
+    }
+    hipLaunchKernelGGL(sk_extract_kernel<K>, dim3(grid), dim3(SK_THREADS), lds, h->stream, d_packed, d_invalid, n_bases, plan, s, slabs_per_wg);
+    return KDF_OK;
+}
+
+static int sk_spill_flush(kdf_engine *h, const SkScratch &s, uint64_t n_spill) {
+    if (n_spill == 0) return KDF_OK;
+    int rc = ovf_ensure(h, n_spill);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sk_spill_insert_kernel, dim3((unsigned)((n_spill + 255) / 256)), dim3(256), 0, h->stream, s, h->t, h->ctl);
+    HIPCHK(h, hipGetLastError());
+    h->ovf_used_ub += n_spill;
+    h->stat_sk_spills += n_spill;
+    return KDF_OK;
+}
+
+// one pass of the super-k-mer pipeline over a device-resident stream (insert mode, SK-layout table).
+// dense: size the chunk pool for one record per position (after a pass ran out of chunks).
+static int sk_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases, bool dense) {
+    if (n_bases == 0) return KDF_OK;
+    int rc;
+    if ((rc = sk_ctrs_init(h))) return rc;
+    SkPlan plan = sk_make_plan(h->t, h->k);
+    plan.key_parts = h->t.key_parts; plan.key_part = h->t.key_part; plan.dbg = h->opt_debug_flags;
+    const uint32_t nbins = 1u << plan.c1;
+    const uint64_t n_slabs = (n_bases + SK_SLAB - 1) / SK_SLAB;
+    uint32_t grid_s1 = (uint32_t)std::min<uint64_t>(n_slabs, (uint64_t)h->n_cu);
+    const uint32_t slabs_per_wg = (uint32_t)((n_slabs + grid_s1 - 1) / grid_s1);
+    grid_s1 = (uint32_t)((n_slabs + slabs_per_wg - 1) / slabs_per_wg);
+    const uint64_t W = (uint64_t)h->k - KDF_SK_M + 1;
+    const uint64_t rec_cap = dense ? n_bases + 65536 : std::min<uint64_t>(n_bases, n_bases * 3 / (W + 1)) + 65536;
+    const uint64_t max_chunks64 = rec_cap / SK_CHUNK + (uint64_t)grid_s1 * nbins + 64;
+    const uint64_t max_groups64 = max_chunks64 / SK_GROUP + nbins + 1;
+    if (max_groups64 * SK_GREC >= (1ull << 32)) return fail(h, KDF_ERR_INVALID, "super-k-mer pass: %llu positions are too many for one pass", (unsigned long long)n_bases);
+    const uint64_t nb_table = 1ull << (plan.c1 + plan.c2 + plan.sub_bits);
+    SkScratch s{};
+    s.max_chunks = (uint32_t)max_chunks64; s.max_groups = (uint32_t)max_groups64;
+    if ((rc = sk_reserve(h, SKB_CHUNKS, max_chunks64 * SK_CHUNK * sizeof(SkRec)))) return rc;
+    if ((rc = sk_reserve(h, SKB_CBIN, max_chunks64 * 4))) return rc;
+    if ((rc = sk_reserve(h, SKB_CPOS, max_chunks64 * 4))) return rc;
+    if ((rc = sk_reserve(h, SKB_CFILL, max_chunks64 * 4))) return rc;
+    if ((rc = sk_reserve(h, SKB_CLIST, max_chunks64 * 4))) return rc;
+    const size_t small_words = 3 * ((size_t)(1 << SK_C1_MAX) + 1);
+    if ((rc = sk_reserve(h, SKB_SMALL, small_words * 4))) return rc;
+    if ((rc = sk_reserve(h, SKB_SORTED, max_groups64 * SK_GREC * sizeof(SkRec)))) return rc;
+    if ((rc = sk_reserve(h, SKB_GOFF, max_groups64 * plan.goff_stride * 4))) return rc;
+    const size_t failed_bytes = (size_t)((nb_table + 31) / 32) * 4;
+    if ((rc = sk_reserve(h, SKB_FAILED, failed_bytes))) return rc;
+    const uint32_t sp_cap0 = 1u << 20;
+    if (h->sk_bytes[SKB_SPKEY] < (size_t)sp_cap0 * 8) { if ((rc = sk_reserve(h, SKB_SPKEY, (size_t)sp_cap0 * 8))) return rc; }
+    if (h->sk_bytes[SKB_SPCNT] < (size_t)sp_cap0 * 4) { if ((rc = sk_reserve(h, SKB_SPCNT, (size_t)sp_cap0 * 4))) return rc; }
+    s.chunks = (SkRec *)h->sk_buf[SKB_CHUNKS];
+    s.chunk_bin = (uint32_t *)h->sk_buf[SKB_CBIN]; s.chunk_pos = (uint32_t *)h->sk_buf[SKB_CPOS];
+    s.chunk_fill = (uint32_t *)h->sk_buf[SKB_CFILL]; s.chunk_list = (uint32_t *)h->sk_buf[SKB_CLIST];
+    s.bin_nchunks = (uint32_t *)h->sk_buf[SKB_SMALL];
+    s.bin_chunk_start = s.bin_nchunks + (1 << SK_C1_MAX) + 1;
+    s.group_first = s.bin_chunk_start + (1 << SK_C1_MAX) + 1;
+    s.sorted = (SkRec *)h->sk_buf[SKB_SORTED]; s.goff = (uint32_t *)h->sk_buf[SKB_GOFF];
+    s.failed = (uint32_t *)h->sk_buf[SKB_FAILED];
+    s.sp_key = (uint64_t *)h->sk_buf[SKB_SPKEY]; s.sp_cnt = (uint32_t *)h->sk_buf[SKB_SPCNT];
+    s.sp_cap = (uint32_t)std::min<uint64_t>(h->sk_bytes[SKB_SPKEY] / 8, h->sk_bytes[SKB_SPCNT] / 4);
+    s.ctrs = h->sk_ctrs;
+    HIPCHK(h, hipMemsetAsync(h->sk_ctrs, 0, SKC_N * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(s.bin_nchunks, 0, small_words * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(s.failed, 0, failed_bytes, h->stream));
+
+    const size_t lds_s1 = (size_t)SK_WPT * SK_THREADS * 4 + (size_t)SK_CAP * 20 + (size_t)(4 * (1 << SK_C1_MAX) + 2 + 40) * 4 + (size_t)(2 * SK_THREADS + 4) * 2 + 16;
+    const size_t lds_s2 = (size_t)SK_GREC * 16 + (size_t)(2 * (1 << SK_C2_MAX) + 40 + 2 * SK_GROUP) * 4;
+    const size_t B = (size_t)1 << plan.bucket_bits;
+    const size_t lds_s3 = B * 12 + (size_t)SK_C_RC * 18 + (size_t)SK_C_SQ * 12 + 16 + (size_t)SK_C_DT * 4 + (size_t)(2 * SK_C_RUNS + 1 + 40 + 8) * 4 + 16;
+    if (!h->sk_attrs_set[0]) {
+        HIPCHK(h, hipFuncSetAttribute((const void *)sk_finesort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s2));
+        HIPCHK(h, hipFuncSetAttribute((const void *)sk_bucket_kernel<SK_MODE_COUNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(12 * 2048 + lds_s3 - B * 12)));
+        HIPCHK(h, hipFuncSetAttribute((const void *)sk_bucket_kernel<SK_MODE_REPLAY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(12 * 2048 + lds_s3 - B * 12)));
+        h->sk_attrs_set[0] = true;
+    }
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::vector<hipEvent_t> sev;
+    auto stamp = [&]() { if (h->prof) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, h->stream); sev.push_back(e); } };
+    if (h->prof) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, h->stream); }
+    stamp();
+    switch (h->k) {
+#define SK_CASE(KK) case KK: rc = sk_launch_extract<KK>(h, grid_s1, lds_s1, d_packed, d_invalid, n_bases, plan, s, slabs_per_wg); break;
+        SK_CASE(16) SK_CASE(17) SK_CASE(18) SK_CASE(19) SK_CASE(20) SK_CASE(21) SK_CASE(22) SK_CASE(23) SK_CASE(24)
+        SK_CASE(25) SK_CASE(26) SK_CASE(27) SK_CASE(28) SK_CASE(29) SK_CASE(30) SK_CASE(31) SK_CASE(32)
+#undef SK_CASE
+        default: rc = fail(h, KDF_ERR_INVALID, "super-k-mer path: k=%d outside %d..32", h->k, SK_MIN_K);
+    }
+    if (rc) return rc;
+    stamp();                                                   // end of S1
+    hipLaunchKernelGGL(sk_binscan_kernel, dim3(1), dim3(1024), 0, h->stream, plan, s);
+    hipLaunchKernelGGL(sk_chunklist_kernel, dim3((unsigned)((max_chunks64 + 255) / 256)), dim3(256), 0, h->stream, s);
+    stamp();                                                   // end of K1
+    hipLaunchKernelGGL(sk_finesort_kernel, dim3(s.max_groups), dim3(SK_THREADS), lds_s2, h->stream, plan, s);
+    stamp();                                                   // end of S2
+    const int nonempty = h->lazy_empty ? 0 : 1;
+    hipLaunchKernelGGL(sk_bucket_kernel<SK_MODE_COUNT>, dim3((unsigned)nb_table), dim3(SK_C_THREADS), lds_s3, h->stream, plan, s, h->t, h->ctl, nonempty);
+    HIPCHK(h, hipGetLastError());
+    if (h->prof) {
+        stamp();                                               // end of S3
+        (void)hipEventRecord(e1, h->stream);
+        h->prof_ev.emplace_back(e0, e1);
+        h->prof_tiles.push_back((n_bases + KDF_TILE - 1) / KDF_TILE);
+        h->prof_stage_ev.push_back(sev);
+    }
+    HIPCHK(h, hipMemcpyAsync(h->sk_ctrs_host, h->sk_ctrs, SKC_N * 4, hipMemcpyDeviceToHost, h->stream));
+    bool full = false;
+    if ((rc = ctl_sync(h, &full))) return rc;
+    const uint32_t *c = h->sk_ctrs_host;
+    if (c[SKC_EXHAUSTED]) { h->stat_sk_fallbacks++; return SK_RC_EXHAUSTED; }          // nothing was inserted
+    h->stat_sk_passes++;
+    h->lazy_empty = false;
+    if (c[SKC_BADNK]) return fail(h, KDF_ERR_STATE, "super-k-mer pass: a record exceeded its window bound (internal error)");
+    if ((rc = sk_spill_flush(h, s, std::min<uint64_t>(c[SKC_SPILL], s.sp_cap)))) return rc;
+    const uint64_t n_failed = c[SKC_FAILED];
+    if (n_failed) {
+        // buckets whose spills did not fit their queue / the list: they are untouched in HBM.  Replay exactly those
+        // with a spill list that holds the worst case (every window of the pass a spill).
+        h->stat_sk_failed += n_failed;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const uint64_t worst = std::min<uint64_t>(n_bases, 0xFFFFFFF0ull);
+        if ((rc = sk_reserve(h, SKB_SPKEY, worst * 8))) return rc;
+        if ((rc = sk_reserve(h, SKB_SPCNT, worst * 4))) return rc;
+        s.sp_key = (uint64_t *)h->sk_buf[SKB_SPKEY]; s.sp_cnt = (uint32_t *)h->sk_buf[SKB_SPCNT];
+        s.sp_cap = (uint32_t)worst;
+        HIPCHK(h, hipMemsetAsync(h->sk_ctrs + SKC_SPILL, 0, 4, h->stream));
+        hipLaunchKernelGGL(sk_bucket_kernel<SK_MODE_REPLAY>, dim3((unsigned)nb_table), dim3(SK_C_THREADS), lds_s3, h->stream, plan, s, h->t, h->ctl, 1);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(h->sk_ctrs_host, h->sk_ctrs, SKC_N * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (c[SKC_SPILL_LOST]) return fail(h, KDF_ERR_STATE, "super-k-mer replay: spill list overflow (internal error)");
+        if ((rc = sk_spill_flush(h, s, std::min<uint64_t>(c[SKC_SPILL], s.sp_cap)))) return rc;
+    }
+    if (c[SKC_SPILL] || n_failed) {
+        if ((rc = ctl_sync(h, &full))) return rc;
+        if (full) return fail(h, KDF_ERR_TABLE_FULL, "super-k-mer pass: overflow table full (internal error)");
+    }
+    return KDF_OK;
+}
+
+// the super-k-mer path over a stream of any length; a range whose chunk pool ran out is redone with a pool sized for
+// one record per position (small ranges) or in halves
+static int sk_passes(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases, int depth = 0) {
+    const uint64_t step = std::min<uint64_t>(h->opt_binned_max_positions, 1ull << 31);
+    for (uint64_t off = 0; off < n_bases; off += step) {
+        const uint64_t len = std::min<uint64_t>(step, n_bases - off);
+        const uint64_t *p = d_packed + off / 32, *m = d_invalid + off / 64;
+        int rc = sk_pass(h, p, m, len, false);
+        if (rc == SK_RC_EXHAUSTED) {
+            if (len <= (1ull << 24)) rc = sk_pass(h, p, m, len, true);
+            else if (depth > 40) rc = fail(h, KDF_ERR_STATE, "super-k-mer path: chunk pool exhausted");
+            else {
+                const uint64_t half = (len / 2 + 63) / 64 * 64;
+                const uint64_t save = h->opt_binned_max_positions;
+                h->opt_binned_max_positions = half;
+                rc = sk_passes(h, p, m, len, depth + 1);
+                h->opt_binned_max_positions = save;
+            }
+            if (rc == SK_RC_EXHAUSTED) rc = fail(h, KDF_ERR_STATE, "super-k-mer path: chunk pool exhausted");
+        }
+        if (rc) return rc;
+        if (off + step < n_bases)
+            while (h->distinct * 10 > h->cap * 7)
+                if ((rc = table_rehash(h, h->t.log2cap + 1))) return rc;
+    }
+    return KDF_OK;
+}
+
+static bool use_sk(const kdf_engine *h, uint64_t n_bases) {
+    if (h->kw != 1 || h->k < SK_MIN_K) return false;
+    if (h->t.sk) return true;                                   // an SK-layout table takes every batch through this path
+    if (h->filter_mode || h->distinct != 0) return false;       // layouts change only on an empty table
+    if (h->opt_force_path == 3) return true;
+    if (h->opt_force_path != 0) return false;
+    return (uint32_t)h->k >= h->opt_sk_min_k && n_bases >= h->opt_binned_min_positions;
+}
+
+
+// (key, count) pairs resident in HBM into the live SK table: bucket first, the rest through the spill list
+static int sk_insert_pairs(kdf_engine *h, const uint64_t *d_lo, const uint32_t *d_cnt, uint64_t n, int skip_empty, uint64_t spill_room,
+                           SkScratch &s, bool reset_ctrs) {
+    int rc;
+    if ((rc = sk_ctrs_init(h))) return rc;
+    spill_room = std::min<uint64_t>(std::max<uint64_t>(spill_room, 1), 0xFFFFFFF0ull);
+    if ((rc = sk_reserve(h, SKB_SPKEY, spill_room * 8))) return rc;
+    if ((rc = sk_reserve(h, SKB_SPCNT, spill_room * 4))) return rc;
+    s.sp_key = (uint64_t *)h->sk_buf[SKB_SPKEY]; s.sp_cnt = (uint32_t *)h->sk_buf[SKB_SPCNT];
+    s.sp_cap = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(h->sk_bytes[SKB_SPKEY] / 8, h->sk_bytes[SKB_SPCNT] / 4), 0xFFFFFFF0ull);
+    s.ctrs = h->sk_ctrs;
+    if (reset_ctrs) HIPCHK(h, hipMemsetAsync(h->sk_ctrs, 0, SKC_N * 4, h->stream));
+    if (n) hipLaunchKernelGGL(sk_insert_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, d_lo, d_cnt, n, h->t, h->ctl, s, skip_empty);
+    HIPCHK(h, hipGetLastError());
+    return KDF_OK;
+}
+static int sk_insert_finish(kdf_engine *h, SkScratch &s) {
+    HIPCHK(h, hipMemcpyAsync(h->sk_ctrs_host, h->sk_ctrs, SKC_N * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->sk_ctrs_host[SKC_SPILL_LOST]) return fail(h, KDF_ERR_STATE, "SK insert: spill list overflow (internal error)");
+    int rc = sk_spill_flush(h, s, std::min<uint64_t>(h->sk_ctrs_host[SKC_SPILL], s.sp_cap));
+    if (rc) return rc;
+    bool full = false;
+    if ((rc = ctl_sync(h, &full))) return rc;
+    if (full) return fail(h, KDF_ERR_TABLE_FULL, "SK insert: overflow table full (internal error)");
+    return KDF_OK;
+}
+
+// grow an SK-layout table: a new table with more buckets (the minimizers are dealt out afresh by their order
+// value's top bits), every key of the old bucket array and of the old overflow array re-inserted
+static int sk_table_rehash(kdf_engine *h, uint32_t new_log2) {
+    int rc = ctl_sync(h, nullptr);
+    if (rc) return rc;
+    const uint64_t windows = h->windows, n_keys = h->lazy_empty ? 0 : h->distinct;
+    KdfTable nt;
+    rc = table_alloc(h, new_log2, nt);
+    if (rc) { table_free(nt); return rc; }
+    nt.sk = 1; nt.k = (uint32_t)h->k; nt.bucket_bits = std::min<uint32_t>(new_log2, 11);
+    nt.key_parts = h->opt_key_parts; nt.key_part = h->opt_key_part;
+    if ((rc = ovf_alloc(h, nt, std::max<uint32_t>(16, h->t.ovf_lo ? h->t.ovf_log2cap : 16)))) { table_free(nt); return rc; }
+    KdfTable old = h->t;
+    h->t = nt; h->cap = 1ull << new_log2;
+    const uint64_t old_ovf_used = h->ovf_used_ub;
+    h->ovf_used_ub = 0;
+    if ((rc = ctl_reset(h, false))) return rc;
+    if (n_keys) {
+        SkScratch s{};
+        if ((rc = sk_insert_pairs(h, old.lo, old.cnt, 1ull << old.log2cap, 1, n_keys, s, true))) return rc;
+        if (old.ovf_lo && old_ovf_used)
+            if ((rc = sk_insert_pairs(h, old.ovf_lo, old.ovf_cnt, 1ull << old.ovf_log2cap, 1, n_keys, s, false))) return rc;
+        if ((rc = sk_insert_finish(h, s))) return rc;
+    } else {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->distinct = 0;
+    }
+    h->lazy_empty = false;
+    table_free(old);
+    h->windows = windows;
+    HIPCHK(h, hipMemcpyAsync(&h->ctl->windows[0], &h->windows, 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return KDF_OK;
+}
+
 static bool use_binned(const kdf_engine *h, uint64_t n_bases, bool filtered) {
     if (h->t.log2cap <= h->t.bucket_bits) return false;        // a single bucket: nothing to partition
     if (h->opt_force_path == 1) return false;
@@ -652,7 +1010,19 @@ static int count_insert_dev(kdf_engine *h, const uint64_t *d_packed, const uint6
     if (h->filter_mode) return fail(h, KDF_ERR_STATE, "kdf_count_reads: a filter is loaded; call kdf_clear first");
     h->t.key_parts = h->opt_key_parts; h->t.key_part = h->opt_key_part;       // (tables are re-created by reserve / rehash: set per call)
     const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
+    if (h->opt_force_path == 3 && (h->kw != 1 || h->k < SK_MIN_K))
+        return fail(h, KDF_ERR_INVALID, "force_path 3 (super-k-mer) needs %d <= k <= 32", SK_MIN_K);
+    if (use_sk(h, n_bases)) {
+        int rc = sk_enter(h);
+        if (rc) return rc;
+        h->last_path = 2;
+        if ((rc = sk_passes(h, d_packed, d_invalid, n_bases))) return rc;
+        while (h->distinct * 10 > h->cap * 7)
+            if ((rc = table_rehash(h, h->t.log2cap + 1))) return rc;
+        return KDF_OK;
+    }
     if (use_binned(h, n_bases, false)) {
+        h->last_path = 1;
         int rc = kb_passes(h, d_packed, d_invalid, n_bases, false);
         if (rc) return rc;
         // keep the load <= 0.7 for the next batch (a 2048-slot bucket then holds
@@ -663,6 +1033,7 @@ static int count_insert_dev(kdf_engine *h, const uint64_t *d_packed, const uint6
         return KDF_OK;
     }
     { int rc0 = materialize(h); if (rc0) return rc0; }
+    h->last_path = 0;
     uint64_t tile = 0;
     while (tile < n_tiles) {
         uint64_t room = (h->cap / 10) * 8 > h->distinct ? (h->cap / 10) * 8 - h->distinct : 0;
@@ -764,6 +1135,9 @@ void kdf_destroy(kdf_engine *h) {
     prof_collect(h);
     for (int i = 0; i < 4; ++i) if (h->stage[i]) (void)hipFree(h->stage[i]);
     for (int i = 0; i < 6; ++i) if (h->kb_buf[i]) (void)hipFree(h->kb_buf[i]);
+    for (int i = 0; i < 16; ++i) if (h->sk_buf[i]) (void)hipFree(h->sk_buf[i]);
+    if (h->sk_ctrs) (void)hipFree(h->sk_ctrs);
+    if (h->sk_ctrs_host) (void)hipHostFree(h->sk_ctrs_host);
     if (h->kb_small) (void)hipFree(h->kb_small);
     if (h->kb_totals_host) (void)hipHostFree(h->kb_totals_host);
     if (h->ctl) (void)hipFree(h->ctl);
@@ -794,6 +1168,7 @@ int kdf_clear(kdf_engine *h) {
     if (rc) return rc;
     h->distinct = 0; h->windows = 0; h->filter_mode = false;
     h->lazy_empty = true;
+    sk_leave(h);                  // layouts are chosen per table generation: the next count decides again
     return KDF_OK;
 }
 
@@ -838,10 +1213,8 @@ int kdf_count_reads(kdf_engine *h, const uint64_t *packed, const uint64_t *inval
     return count_insert_dev(h, dp, dm, n_bases);
 }
 
-int kdf_load_filter(kdf_engine *h, const uint64_t *keys_lo, const uint64_t *keys_hi, uint64_t n) {
-    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
-    if (n && (!keys_lo || (h->kw == 2 && !keys_hi))) return fail(h, KDF_ERR_INVALID, "kdf_load_filter: NULL keys");
-    HIPCHK(h, hipSetDevice(h->device));
+// the table becomes exactly the n keys at d_lo / d_hi (device arrays) with count 0
+static int load_filter_core(kdf_engine *h, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t n) {
     int rc;
     // size the table for n keys at load <= 0.5, then start from empty
     const uint32_t want = cap_log2_for(n);
@@ -851,28 +1224,57 @@ int kdf_load_filter(kdf_engine *h, const uint64_t *keys_lo, const uint64_t *keys
         if ((rc = table_alloc(h, want, h->t))) return rc;
         h->cap = 1ull << want;
         if ((rc = ctl_reset(h, false))) return rc;
-        h->distinct = 0; h->windows = 0; h->lazy_empty = false; h->filter_mode = false;
+        h->distinct = 0; h->windows = 0; h->lazy_empty = false; h->filter_mode = false; h->ovf_used_ub = 0;
     } else if ((rc = kdf_clear(h))) return rc;
     if ((rc = materialize(h))) return rc;
     h->filter_mode = true;
     if (n == 0) return KDF_OK;
-    if ((rc = stage_reserve(h, 2, n * 8))) return rc;
-    HIPCHK(h, hipMemcpyAsync(h->stage[2], keys_lo, n * 8, hipMemcpyHostToDevice, h->stream));
-    if (h->kw == 2) {
-        if ((rc = stage_reserve(h, 3, n * 8))) return rc;
-        HIPCHK(h, hipMemcpyAsync(h->stage[3], keys_hi, n * 8, hipMemcpyHostToDevice, h->stream));
-    }
     const unsigned blocks = (unsigned)((n + 255) / 256);
     if (h->kw == 1)
         hipLaunchKernelGGL(kdf_insert_keys_kernel<1>, dim3(blocks), dim3(256), 0, h->stream,
-                           (const uint64_t *)h->stage[2], (const uint64_t *)nullptr, (const uint32_t *)nullptr, n, h->t, h->ctl, 0);
+                           d_lo, (const uint64_t *)nullptr, (const uint32_t *)nullptr, n, h->t, h->ctl, 0);
     else
         hipLaunchKernelGGL(kdf_insert_keys_kernel<2>, dim3(blocks), dim3(256), 0, h->stream,
-                           (const uint64_t *)h->stage[2], (const uint64_t *)h->stage[3], (const uint32_t *)nullptr, n, h->t, h->ctl, 0);
+                           d_lo, d_hi, (const uint32_t *)nullptr, n, h->t, h->ctl, 0);
     HIPCHK(h, hipGetLastError());
     bool full = false;
     if ((rc = ctl_sync(h, &full))) return rc;
     if (full) return fail(h, KDF_ERR_TABLE_FULL, "kdf_load_filter: bucket overflow");
+    return KDF_OK;
+}
+
+int kdf_load_filter(kdf_engine *h, const uint64_t *keys_lo, const uint64_t *keys_hi, uint64_t n) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    if (n && (!keys_lo || (h->kw == 2 && !keys_hi))) return fail(h, KDF_ERR_INVALID, "kdf_load_filter: NULL keys");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if (n) {
+        if ((rc = stage_reserve(h, 2, n * 8))) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->stage[2], keys_lo, n * 8, hipMemcpyHostToDevice, h->stream));
+        if (h->kw == 2) {
+            if ((rc = stage_reserve(h, 3, n * 8))) return rc;
+            HIPCHK(h, hipMemcpyAsync(h->stage[3], keys_hi, n * 8, hipMemcpyHostToDevice, h->stream));
+        }
+    }
+    return load_filter_core(h, (const uint64_t *)h->stage[2], (const uint64_t *)h->stage[3], n);
+}
+
+int kdf_load_filter_dev(kdf_engine *h, const void *d_keys_lo, const void *d_keys_hi, uint64_t n) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    if (n && (!d_keys_lo || (h->kw == 2 && !d_keys_hi))) return fail(h, KDF_ERR_INVALID, "kdf_load_filter_dev: NULL keys");
+    HIPCHK(h, hipSetDevice(h->device));
+    return load_filter_core(h, (const uint64_t *)d_keys_lo, (const uint64_t *)d_keys_hi, n);
+}
+
+int kdf_reset_counts(kdf_engine *h) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = materialize(h);
+    if (rc) return rc;
+    HIPCHK(h, hipMemsetAsync(h->t.cnt, 0, h->cap * 4, h->stream));
+    if (h->t.sk && h->t.ovf_cnt) HIPCHK(h, hipMemsetAsync(h->t.ovf_cnt, 0, (1ull << h->t.ovf_log2cap) * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->ctl->windows, 0, sizeof(h->ctl->windows), h->stream));
+    h->windows = 0;
     return KDF_OK;
 }
 
@@ -885,6 +1287,11 @@ static int add_pairs_dev(kdf_engine *h, const uint64_t *d_lo, const uint64_t *d_
     if ((rc = ctl_sync(h, nullptr))) return rc;
     const uint32_t want = cap_log2_for(h->distinct + n);
     if (want > h->t.log2cap && (rc = table_rehash(h, want))) return rc;
+    if (h->t.sk) {
+        SkScratch s{};
+        if ((rc = sk_insert_pairs(h, d_lo, d_cnt, n, 0, n, s, true))) return rc;
+        return sk_insert_finish(h, s);
+    }
     const unsigned blocks = (unsigned)((n + 255) / 256);
     if (h->kw == 1)
         hipLaunchKernelGGL(kdf_insert_keys_kernel<1>, dim3(blocks), dim3(256), 0, h->stream, d_lo, (const uint64_t *)nullptr, d_cnt, n, h->t, h->ctl, 0);
@@ -1001,6 +1408,14 @@ static int export_pass(kdf_engine *h, uint32_t min_count, bool write, uint64_t *
         if (write) hipLaunchKernelGGL((kdf_export_kernel<2, true>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap, parts);
         else hipLaunchKernelGGL((kdf_export_kernel<2, false>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap, parts);
     }
+    if (h->t.sk && h->t.ovf_lo && h->ovf_used_ub) {         // the overflow array is part of the table
+        KdfTable ov{};
+        ov.lo = h->t.ovf_lo; ov.cnt = h->t.ovf_cnt; ov.log2cap = h->t.ovf_log2cap; ov.bucket_bits = ov.log2cap;
+        const uint64_t ow = ((1ull << ov.log2cap) + KDF_EXPORT_ROWS * 64 - 1) / (KDF_EXPORT_ROWS * 64);
+        const unsigned ob = (unsigned)((ow + 3) / 4);
+        if (write) hipLaunchKernelGGL((kdf_export_kernel<1, true>), dim3(ob), dim3(256), 0, h->stream, ov, min_count, h->ctl, olo, ohi, ocnt, out_cap, 0u);
+        else hipLaunchKernelGGL((kdf_export_kernel<1, false>), dim3(ob), dim3(256), 0, h->stream, ov, min_count, h->ctl, olo, ohi, ocnt, out_cap, 0u);
+    }
     HIPCHK(h, hipGetLastError());
     if (parts) {                                            // per-part tallies (count pass) / end cursors (write pass)
         stage.assign(KDF_SHARDS * 16, 0ull);
@@ -1024,6 +1439,7 @@ int kdf_export_parts_dev(kdf_engine *h, uint32_t min_count, uint32_t parts, void
     if (parts < 1 || parts > KDF_SHARDS) return fail(h, KDF_ERR_INVALID, "kdf_export_parts_dev: parts must be 1..%d", KDF_SHARDS);
     HIPCHK(h, hipSetDevice(h->device));
     { int rc0 = materialize(h); if (rc0) return rc0; }
+    if (h->t.sk) return fail(h, KDF_ERR_STATE, "kdf_export_parts_dev: the table is minimizer-bucketed (owners are not slot ranges)");
     if (h->t.log2cap < 16 + std::max<uint32_t>(11, h->t.bucket_bits))
         return fail(h, KDF_ERR_STATE, "kdf_export_parts_dev: table of 2^%u slots is too small for an owner-ordered dump (needs 2^%u)",
                     h->t.log2cap, 16 + std::max<uint32_t>(11, h->t.bucket_bits));
@@ -1097,20 +1513,17 @@ int kdf_export_ge_dev(kdf_engine *h, uint32_t min_count, void *d_keys_lo_out, vo
                       void *d_counts_out, uint64_t cap, int sorted, uint64_t *n_out) {
     if (!h || !n_out) return fail(h, KDF_ERR_INVALID, "kdf_export_ge_dev: NULL pointer");
     HIPCHK(h, hipSetDevice(h->device));
+    if (cap && (!d_keys_lo_out || (h->kw == 2 && !d_keys_hi_out))) return fail(h, KDF_ERR_INVALID, "kdf_export_ge_dev: NULL key output");
+    // ONE pass over the table: entries are appended through the cursor, nothing is written past `cap`, and the
+    // cursor's final value is the number of entries the dump holds (kdf_count_ge gives it beforehand)
     uint64_t n = 0;
-    int rc = export_pass(h, min_count, false, nullptr, nullptr, nullptr, 0, &n);
+    int rc = export_pass(h, min_count, true, (uint64_t *)d_keys_lo_out, h->kw == 2 ? (uint64_t *)d_keys_hi_out : nullptr,
+                         (uint32_t *)d_counts_out, cap, &n);
     if (rc) return rc;
     *n_out = n;
-    if (n == 0) return KDF_OK;
     if (n > cap) return fail(h, KDF_ERR_INVALID, "kdf_export_ge_dev: %llu entries, room for %llu",
                              (unsigned long long)n, (unsigned long long)cap);
-    if (!d_keys_lo_out || (h->kw == 2 && !d_keys_hi_out)) return fail(h, KDF_ERR_INVALID, "kdf_export_ge_dev: NULL key output");
-    uint64_t n2 = 0;
-    rc = export_pass(h, min_count, true, (uint64_t *)d_keys_lo_out, h->kw == 2 ? (uint64_t *)d_keys_hi_out : nullptr,
-                     (uint32_t *)d_counts_out, n, &n2);
-    if (rc) return rc;
-    if (n2 != n) return fail(h, KDF_ERR_STATE, "kdf_export_ge_dev: table changed between passes");
-    if (sorted) {
+    if (sorted && n) {
         if (!d_counts_out) return fail(h, KDF_ERR_INVALID, "kdf_export_ge_dev: sorted export needs the counts array");
         std::string serr;
         if (kdf_sort_pairs_device((uint64_t *)d_keys_lo_out, h->kw == 2 ? (uint64_t *)d_keys_hi_out : nullptr,
@@ -1236,6 +1649,7 @@ int kdf_set_option(kdf_engine *h, const char *name, int64_t value) {
     }
     else if (n == "binned_filtered_min_log2cap") h->opt_binned_filtered_min_log2cap = (uint32_t)value;
     else if (n == "force_path") h->opt_force_path = (int)value;
+    else if (n == "sk_min_k") h->opt_sk_min_k = (uint32_t)value;
     else if (n == "debug_flags") h->opt_debug_flags = (uint32_t)value;
     else return fail(h, KDF_ERR_INVALID, "kdf_set_option: unknown option %s", name);
     return KDF_OK;
@@ -1247,6 +1661,13 @@ int kdf_get_stat(kdf_engine *h, const char *name, int64_t *value) {
     if (n == "binned_passes") *value = (int64_t)h->stat_binned_passes;
     else if (n == "replayed_buckets") *value = (int64_t)h->stat_replayed_buckets;
     else if (n.rfind("dbg_t", 0) == 0 && n.size() == 6 && n[5] >= '0' && n[5] <= '5') *value = (int64_t)h->stat_dbg[n[5] - '0'];
+    else if (n == "sk_passes") *value = (int64_t)h->stat_sk_passes;
+    else if (n == "sk_spills") *value = (int64_t)h->stat_sk_spills;
+    else if (n == "sk_failed_buckets") *value = (int64_t)h->stat_sk_failed;
+    else if (n == "sk_fallbacks") *value = (int64_t)h->stat_sk_fallbacks;
+    else if (n == "layout") *value = h->t.sk ? 1 : 0;
+    else if (n == "last_count_path") *value = h->last_path;
+    else if (n == "ovf_log2cap") *value = h->t.ovf_lo ? (int64_t)h->t.ovf_log2cap : 0;
     else if (n == "log2cap") *value = h->t.log2cap;
     else if (n == "bucket_bits") *value = h->t.bucket_bits;
     else return fail(h, KDF_ERR_INVALID, "kdf_get_stat: unknown stat %s", name);

@@ -109,7 +109,7 @@ class EngineOps(TableOps):
     def export_pairs_by_owner(self, world: int):
         """(lo, hi, cnt, per-owner counts) already grouped by owner rank, or None when
         the table is too small for the engine's owner-ordered dump."""
-        if self.e.get_stat("log2cap") < 16 + max(11, self.e.get_stat("bucket_bits")) or world > 64:
+        if self.e.get_stat("layout") != 0 or self.e.get_stat("log2cap") < 16 + max(11, self.e.get_stat("bucket_bits")) or world > 64:
             return None
         _, distinct, _ = self.e.stats()
         lo = torch.empty(distinct, dtype=torch.int64, device=self.device)
@@ -155,18 +155,43 @@ def _u32(t: torch.Tensor) -> torch.Tensor:
 class ShardedFilterCount:
     """count --if over a read stream sharded across ranks, merged by one all-reduce."""
 
-    def __init__(self, ops: TableOps, group=None):
+    def __init__(self, ops: TableOps, group=None, stage_through_host: bool = False):
         self.ops = ops
         self.group = group
+        self.host = stage_through_host
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.last_reduce_dtype = None
 
     def merged_counts(self, keys_lo: torch.Tensor, keys_hi: Optional[torch.Tensor]) -> torch.Tensor:
-        """Global count of every filter key (same key order on every rank),
-        saturating at 2^32-1.  Call after each rank counted its own shard."""
-        local = _u32(self.ops.query(keys_lo, keys_hi))            # int64: the sum cannot wrap
-        if self.world > 1 and local.numel():
-            dist.all_reduce(local, op=dist.ReduceOp.SUM, group=self.group)
-        return torch.clamp(local, max=_U32_MAX)
+        """Global count of every filter key (same key order on every rank), saturating at
+        2^32-1, as int64 values.  Call after each rank counted its own shard.
+
+        The counts travel as ONE all-reduce(sum) of 4-byte words (the `ncclUint32` reduce of
+        SURVEY.md section 8e): a scalar all-reduce(max) of the largest local count first
+        proves that world x max < 2^32, i.e. that the 32-bit sums cannot wrap.  Only when
+        that fails (counts near Jellyfish's 4-byte ceiling) the sum is taken in 8-byte words
+        and clamped."""
+        local32 = self.ops.query(keys_lo, keys_hi)                 # int32 bit patterns of uint32 counts
+        if self.world == 1 or local32.numel() == 0:
+            return _u32(local32)
+        if self.host:
+            local32 = local32.cpu()
+        mx = _u32(local32).max().reshape(1)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
+        if int(mx.item()) * self.world <= _U32_MAX:
+            dist.all_reduce(local32, op=dist.ReduceOp.SUM, group=self.group)   # wraps like uint32: proven not to
+            self.last_reduce_dtype = torch.int32
+            out = _u32(local32)
+        else:
+            wide = _u32(local32)
+            dist.all_reduce(wide, op=dist.ReduceOp.SUM, group=self.group)
+            self.last_reduce_dtype = torch.int64
+            out = torch.clamp(wide, max=_U32_MAX)
+        return out.to(keys_lo.device) if self.host else out
+
+
+def _round8(n: int) -> int:
+    return (n + 7) & ~7
 
 
 class OwnerPartitionedCount:
@@ -186,8 +211,13 @@ class OwnerPartitionedCount:
         self.device = device if device is not None else local_ops.device
         if owner_ops is None and make_owner_ops is not None:
             owner_ops = make_owner_ops()
+        if self.world > 1 and owner_ops is None:
+            # summing the received pairs into the table that still holds the local partial counts would
+            # count this rank's own keys twice and keep the keys it does not own
+            raise ValueError("OwnerPartitionedCount: with more than one rank the owner-side table "
+                             "(owner_ops or make_owner_ops) must be distinct from the local one")
         # with one rank the local table already is the global one
-        self.owner = owner_ops if (owner_ops is not None and self.world > 1) else local_ops
+        self.owner = owner_ops if self.world > 1 else local_ops
         self._local_stats = (0, 0, 0)
         self.last_exchange_pairs = 0
 
@@ -195,39 +225,59 @@ class OwnerPartitionedCount:
         return self._local_stats
 
     def exchange(self):
-        """Move every locally counted (key, count) pair to its owner rank."""
+        """Move every locally counted (key, count) pair to its owner rank: one count exchange and ONE
+        packed all-to-all (per destination a byte segment [lo words | hi words | counts], starts aligned to 8)."""
         if self.world == 1:
             return
         grouped = self.local.export_pairs_by_owner(self.world) if hasattr(self.local, "export_pairs_by_owner") else None
         if grouped is not None:                      # the engine dumps owner by owner: nothing to sort
             lo, hi, cnt, counts = grouped
-            send_counts = torch.tensor(counts, dtype=torch.int64, device=self.device)
+            send_counts = torch.tensor(counts, dtype=torch.int64)
         else:
             lo, hi, cnt = self.local.export_pairs(0)
             own = owner_of(lo, hi, self.world)
             order = torch.argsort(own, stable=True)
             lo, cnt = lo[order], cnt[order]
             hi = hi[order] if hi is not None else None
-            send_counts = torch.bincount(own, minlength=self.world).to(torch.int64)
-        if self.host:
-            send_counts = send_counts.cpu()
-        recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts, group=self.group)
+            send_counts = torch.bincount(own, minlength=self.world).to(torch.int64).cpu()
+        cdev = torch.device("cpu") if self.host else self.device
+        sc = send_counts.to(cdev)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc, group=self.group)
         s_list: List[int] = send_counts.tolist()
-        r_list: List[int] = recv_counts.tolist()
-        n_recv = int(sum(r_list))
+        r_list: List[int] = rc.tolist()
         self.last_exchange_pairs = int(sum(s_list))
-
-        def a2a(t: torch.Tensor) -> torch.Tensor:
-            src = t.contiguous().cpu() if self.host else t.contiguous()
-            out = torch.empty(n_recv, dtype=t.dtype, device=src.device)
-            dist.all_to_all_single(out, src, output_split_sizes=r_list, input_split_sizes=s_list, group=self.group)
-            return out.to(t.device) if self.host else out
-
-        rlo = a2a(lo)
-        rhi = a2a(hi) if hi is not None else None
-        rcnt = a2a(cnt)
-        self.owner.add_pairs(rlo, rhi, rcnt)
+        esz = 20 if hi is not None else 12
+        s_bytes = [_round8(n * esz) for n in s_list]
+        r_bytes = [_round8(n * esz) for n in r_list]
+        send = torch.empty(sum(s_bytes), dtype=torch.uint8, device=lo.device)
+        off = a = 0
+        for n, nb in zip(s_list, s_bytes):           # 2-3 contiguous device copies per destination
+            if n:
+                send[off:off + 8 * n].view(torch.int64).copy_(lo[a:a + n])
+                o2 = off + 8 * n
+                if hi is not None:
+                    send[o2:o2 + 8 * n].view(torch.int64).copy_(hi[a:a + n])
+                    o2 += 8 * n
+                send[o2:o2 + 4 * n].view(torch.int32).copy_(cnt[a:a + n])
+            off += nb
+            a += n
+        src = send.cpu() if self.host else send
+        recv = torch.empty(sum(r_bytes), dtype=torch.uint8, device=src.device)
+        dist.all_to_all_single(recv, src, output_split_sizes=r_bytes, input_split_sizes=s_bytes, group=self.group)
+        if self.host:
+            recv = recv.to(lo.device)
+        off = 0
+        for n, nb in zip(r_list, r_bytes):           # the owner sums source by source, straight from the segments
+            if n:
+                rlo = recv[off:off + 8 * n].view(torch.int64)
+                o2 = off + 8 * n
+                rhi = None
+                if hi is not None:
+                    rhi = recv[o2:o2 + 8 * n].view(torch.int64)
+                    o2 += 8 * n
+                self.owner.add_pairs(rlo, rhi, recv[o2:o2 + 4 * n].view(torch.int32))
+            off += nb
 
     def clear(self):
         self.local.clear()

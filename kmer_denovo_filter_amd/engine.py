@@ -110,6 +110,19 @@ class KmerEngine:
         self._ck(self._lib.kdf_profile_stages(self._h, ms, byref(n)))
         return list(ms), n.value
 
+    _PATHS = ("direct", "binned", "superkmer")
+    _STAGES = {
+        "binned": ["kb_hist1_kernel(+scans)", "kb_scatter1_kernel", "kb_finesort_kernel", "kb_bucket_kernel"],
+        "superkmer": ["sk_extract_kernel", "sk_binscan+sk_chunklist", "sk_finesort_kernel", "sk_bucket_kernel"],
+    }
+
+    def last_count_path(self) -> str:
+        """Which pipeline the last count call took: direct / binned / superkmer."""
+        return self._PATHS[self.get_stat("last_count_path")]
+
+    def profile_stage_names(self):
+        return self._STAGES.get(self.last_count_path(), self._STAGES["binned"])
+
     # -- count / filter ----------------------------------------------------
     def count(self, stream: ReadStream):
         self._ck(self._lib.kdf_count_reads(self._h, _vp(stream.packed), _vp(stream.invalid), stream.n_bases))
@@ -144,6 +157,16 @@ class KmerEngine:
         else:
             hi = None
         self._ck(self._lib.kdf_load_filter(self._h, _vp(lo), _vp(hi), len(lo)))
+        return self
+
+    def load_filter_dev(self, d_lo: int, d_hi: Optional[int], n: int):
+        """Filter keys already resident in HBM (raw device pointers)."""
+        self._ck(self._lib.kdf_load_filter_dev(self._h, c_void_p(d_lo), c_void_p(d_hi) if d_hi else None, int(n)))
+        return self
+
+    def reset_counts(self):
+        """Zero every count, keep the keys (the same filter against the next parent)."""
+        self._ck(self._lib.kdf_reset_counts(self._h))
         return self
 
     def count_filtered(self, stream: ReadStream):

@@ -44,6 +44,7 @@ class OracleOps:
     def clear(self):
         self.t = self.O.OracleTable(self.k, 1 << 12)
         self.windows = 0
+        self._dict = None
 
     @staticmethod
     def _to_t(a, dt):
@@ -62,10 +63,12 @@ class OracleOps:
 
     def add_pairs(self, lo, hi, cnt):
         # insert-or-add through the oracle: load as filter (count 0) then add counts via a dict merge
-        cur = {}
-        l0, h0, c0 = self.t.export_ge(0)
-        for a, b, c in zip(l0.tolist(), h0.tolist(), c0.tolist()):
-            cur[(b, a)] = c
+        cur = getattr(self, "_dict", None)
+        if cur is None:                                   # the exchange calls add_pairs once per source rank
+            cur = {}
+            l0, h0, c0 = self.t.export_ge(0)
+            for a, b, c in zip(l0.tolist(), h0.tolist(), c0.tolist()):
+                cur[(b, a)] = c
         lo_u = lo.numpy().view(np.uint64); hi_u = hi.numpy().view(np.uint64) if hi is not None else np.zeros(len(lo_u), np.uint64)
         for a, b, c in zip(lo_u.tolist(), hi_u.tolist(), (cnt.numpy().view(np.uint32)).tolist()):
             cur[(b, a)] = min(cur.get((b, a), 0) + c, 0xFFFFFFFF)
@@ -86,6 +89,18 @@ class OracleOps:
 
     def items(self):
         return dict(self._dict)
+
+
+class _FixedCounts:
+    """TableOps stub: query() returns fixed uint32 bit patterns (merge arithmetic only)."""
+    device = torch.device("cpu")
+    wide = False
+
+    def __init__(self, counts):
+        self.c = counts
+
+    def query(self, lo, hi):
+        return self.c.clone()
 
 
 def _worker(rank, world, port, k, q):
@@ -118,6 +133,18 @@ def _worker(rank, world, port, k, q):
         tl = torch.from_numpy(flo[sel].view(np.int64).copy())
         th = torch.from_numpy(fhi[sel].view(np.int64).copy()) if k > 32 else None
         merged = sfc.merged_counts(tl, th).numpy()
+        assert sfc.last_reduce_dtype == torch.int32          # the counts travelled as 4-byte words
+        # counts near Jellyfish's 4-byte ceiling: the 32-bit sum would wrap, so the merge falls back to 8-byte words
+        big = _FixedCounts(torch.tensor([0xFFFFFFF0 - (1 << 32), 5, 0], dtype=torch.int32))
+        sb = ShardedFilterCount(big)
+        mb = sb.merged_counts(torch.zeros(3, dtype=torch.int64), None)
+        assert sb.last_reduce_dtype == torch.int64 and mb.tolist() == [0xFFFFFFFF, 5 * world, 0]
+        # a rank-local owner table is mandatory with more than one rank (the default used to double count)
+        try:
+            OwnerPartitionedCount(OracleOps(O, k))
+            raise AssertionError("OwnerPartitionedCount without an owner table must refuse world > 1")
+        except ValueError:
+            pass
         q.put((rank, n_ge2, owned, merged.tolist(), opc.local_stats()[2]))
     finally:
         dist.destroy_process_group()
@@ -168,3 +195,24 @@ def test_owner_function_is_layout_independent():
     lo = torch.arange(0, 100000, dtype=torch.int64)
     frac = torch.bincount(owner_of(lo, None, 8), minlength=8).double() / len(lo)
     assert float((frac - 1 / 8).abs().max()) < 0.05
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher must start N ranks itself, before anything touches the
+    GPU (it used to run one rank and report n_gpus = 1).  --launch-check makes every rank report
+    and exit, so this runs on a CPU-only box."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert sorted(x["rank"] for x in lines) == [0, 1] and all(x["world"] == 2 and x["n_gpus"] == 2 for x in lines)
+    # a launcher that started the wrong number of ranks is an error, not a silent one-rank run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
+                       capture_output=True, text=True, timeout=120, env=env2)
+    assert r.returncode != 0

@@ -1,0 +1,222 @@
+"""GPU parity of the super-k-mer count path (csrc/kdf_sk.h: minimizer-bucketed table, records instead of
+k-mer instances, in-bucket record merge, overflow table) against the oracle, through the C ABI.
+force_path=3 sends every count call through S1/K1/S2/S3 whatever the batch size.  What it replaces:
+`jellyfish count -m k -C` (discovery/pipeline.py:114-172)."""
+import numpy as np
+import pytest
+
+from test_gpu_parity_basic import oracle_sorted, rand_reads
+
+pytestmark = pytest.mark.gpu
+
+M = 12
+
+
+def sk_order(cm):
+    g = (cm * 0x9E3779) & 0xFFFFFF
+    return g ^ (g >> 11)
+
+
+def canon_mmer(code):
+    """canonical 12-mer code (min of the m-mer and its reverse complement, MSB-first 2-bit code)"""
+    rc = 0
+    x = code
+    for _ in range(M):
+        rc = (rc << 2) | (3 - (x & 3))
+        x >>= 2
+    return min(code, rc)
+
+
+def smallest_order_mmer():
+    """the 12-mer (as a string) whose canonical code has the smallest order value: the minimizer of every
+    window that contains it"""
+    codes = np.arange(1 << 24, dtype=np.uint64)
+    g = (codes * 0x9E3779) & 0xFFFFFF
+    g ^= g >> 11
+    order = np.argsort(g, kind="stable")
+    for c in order[:64].tolist():
+        if canon_mmer(c) == c:                       # a canonical code: it really occurs as a minimizer value
+            return "".join("ACGT"[(c >> (2 * (M - 1 - i))) & 3] for i in range(M))
+    raise AssertionError
+
+
+def check_equal(e, oracle, k, reads, lo, hi, cnt):
+    glo, ghi, gcnt = e.export_ge(0)
+    cap, distinct, windows = e.stats()
+    assert windows == oracle.count_windows(reads, k)
+    assert distinct == len(lo)
+    np.testing.assert_array_equal(glo, lo)
+    np.testing.assert_array_equal(ghi, hi)
+    np.testing.assert_array_equal(gcnt, cnt)
+
+
+@pytest.mark.parametrize("k,hint", [(16, 1 << 12), (21, 1 << 20), (27, 1 << 14), (31, 1 << 10), (31, 1 << 17), (32, 1 << 16)])
+def test_superkmer_count_matches_oracle(oracle, k, hint):
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    rng = np.random.default_rng(4000 + k + hint)
+    genome = rng.integers(0, 4, 60000).astype(np.uint8)
+    reads = rand_reads(rng, 3000, 0, 300, genome=genome) + ["", "A" * 500, "N" * 70, "ACGT" * 80, "ACGTTGCA" * 50]
+    t, (lo, hi, cnt) = oracle_sorted(oracle, k, reads)
+    with KmerEngine(k, capacity_hint=hint) as e:
+        e.set_option("force_path", 3)
+        half = len(reads) // 2
+        e.count(ReadStream.from_strings(reads[:half]))         # empty table -> minimizer-bucketed layout
+        assert e.get_stat("layout") == 1 and e.last_count_path() == "superkmer"
+        e.count(ReadStream.from_strings(reads[half:]))         # the second batch finds a non-empty SK table
+        assert e.get_stat("sk_passes") >= 2
+        check_equal(e, oracle, k, reads, lo, hi, cnt)
+        lo2, hi2, c2 = t.export_ge(2)
+        g2 = e.export_ge(2)
+        np.testing.assert_array_equal(g2[0], lo2); np.testing.assert_array_equal(g2[2], c2)
+        # query: present + absent keys, input order (the minimizer is derived from the key)
+        q_lo = np.concatenate([lo[::-1][:300], rng.integers(0, 1 << (2 * k - 2), 100, dtype=np.uint64)])
+        q_hi = np.zeros(len(q_lo), np.uint64)
+        np.testing.assert_array_equal(e.query(q_lo, q_hi), t.query(q_lo, q_hi))
+        # index-load / merge into an SK table: counts add up, new keys appear
+        extra_lo = np.concatenate([lo[:50], np.array([3, 5, 7], np.uint64)])
+        e.add_pairs(extra_lo, np.zeros(len(extra_lo), np.uint64), np.full(len(extra_lo), 9, np.uint32))
+        exp = t.query(extra_lo, np.zeros(len(extra_lo), np.uint64)).astype(np.uint64) + 9
+        np.testing.assert_array_equal(e.query(extra_lo, np.zeros(len(extra_lo), np.uint64)), exp.astype(np.uint32))
+        # kdf_clear returns to the hash layout; a small count then takes the direct path and is still right
+        e.clear(); e.set_option("force_path", 0)
+        assert e.get_stat("layout") == 0
+        e.count(ReadStream.from_strings(reads[:200]))
+        t2, (l2, h2, c2) = oracle_sorted(oracle, k, reads[:200])
+        glo, _, gcnt = e.export_ge(0)
+        np.testing.assert_array_equal(glo, l2); np.testing.assert_array_equal(gcnt, c2)
+
+
+def test_superkmer_scan_and_filter_chain(oracle):
+    """Module-3 scan (hit bit per window) against an SK-layout index, and an SK count feeding a hash-layout filter."""
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    from kmer_denovo_filter_amd.engine import hit_positions
+    k = 31
+    rng = np.random.default_rng(9)
+    genome = rng.integers(0, 4, 40000).astype(np.uint8)
+    child = rand_reads(rng, 1500, 60, 260, genome=genome)
+    probe = rand_reads(rng, 300, 40, 260, genome=genome)
+    t, (lo, hi, cnt) = oracle_sorted(oracle, k, child)
+    with KmerEngine(k, capacity_hint=1 << 14) as e:
+        e.set_option("force_path", 3)
+        e.count(ReadStream.from_strings(child))
+        st = ReadStream.from_strings(probe)
+        hits, distinct = e.scan(st)
+        ohit, odist = t.scan_reads(probe)
+        np.testing.assert_array_equal(distinct, odist)
+        buf_off = 0
+        for r, read in enumerate(probe):
+            s, eoff = int(st.offsets[r]), int(st.offsets[r]) + len(read)
+            np.testing.assert_array_equal(hit_positions(hits, s, eoff), np.nonzero(ohit[buf_off:buf_off + len(read)])[0])
+            buf_off += len(read)
+
+
+def test_superkmer_skew_forced_cuts_and_overflow(oracle):
+    """Homopolymers and tandem repeats keep ONE minimizer value alive for hundreds of windows (records are cut on
+    a grid), and a minimizer that owns far more distinct k-mers than a 2048-slot bucket holds sends its keys
+    to the overflow table through the spill list / the failed-bucket replay."""
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    k = 31
+    rng = np.random.default_rng(5)
+    core = smallest_order_mmer()
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    heavy = []
+    for _ in range(6000):                                   # every window of these reads contains `core`
+        fl = acgt[rng.integers(0, 4, 38)].tobytes().decode()
+        heavy.append(fl[:19] + core + fl[19:])
+    reads = ["A" * 300] * 400 + ["ACACACACAC" * 30] * 300 + ["ACG" * 90] * 50 + heavy + rand_reads(rng, 500, 100, 200)
+    t, (lo, hi, cnt) = oracle_sorted(oracle, k, reads)
+    for hint in (1 << 12, 1 << 18):
+        with KmerEngine(k, capacity_hint=hint) as e:
+            e.set_option("force_path", 3)
+            e.count(ReadStream.from_strings(reads))
+            check_equal(e, oracle, k, reads, lo, hi, cnt)
+            assert int(e.export_ge(0)[2].max()) == 400 * 270
+            assert e.get_stat("sk_spills") > 0 and e.get_stat("ovf_log2cap") >= 16      # the heavy minimizer overflowed its bucket
+            # a second batch into the table that already holds overflow entries
+            e.count(ReadStream.from_strings(reads[:3000]))
+            t2 = oracle.OracleTable(k, 1 << 12).count_reads(reads).count_reads(reads[:3000])
+            l2, h2, c2 = t2.export_ge(0)
+            glo, _, gcnt = e.export_ge(0)
+            np.testing.assert_array_equal(glo, l2); np.testing.assert_array_equal(gcnt, c2)
+            np.testing.assert_array_equal(e.query(l2[::11], h2[::11]), c2[::11])
+        if hint == 1 << 12:
+            continue
+    # the failed-bucket replay: more spills than one bucket may queue
+    with KmerEngine(k, capacity_hint=1 << 18) as e:
+        e.set_option("force_path", 3)
+        e.count(ReadStream.from_strings(heavy))
+        assert e.get_stat("sk_failed_buckets") > 0
+        th, (l3, h3, c3) = oracle_sorted(oracle, k, heavy)
+        glo, _, gcnt = e.export_ge(0)
+        np.testing.assert_array_equal(glo, l3); np.testing.assert_array_equal(gcnt, c3)
+
+
+@pytest.mark.parametrize("k", [21, 31])
+def test_superkmer_stream_walked_in_several_passes(oracle, k):
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    rng = np.random.default_rng(12)
+    genome = rng.integers(0, 4, 30_000).astype(np.uint8)
+    reads = rand_reads(rng, 600, 60, 260, genome=genome)
+    st = ReadStream.from_strings(reads)
+    t, (lo, hi, cnt) = oracle_sorted(oracle, k, reads)
+    with KmerEngine(k, capacity_hint=1 << 15) as e:
+        e.set_option("force_path", 3); e.set_option("binned_max_positions", 8192)
+        e.count(st)
+        assert e.get_stat("sk_passes") == -(-st.n_bases // 8192) > 5
+        check_equal(e, oracle, k, reads, lo, hi, cnt)
+
+
+def test_superkmer_counts_saturate_at_uint32_max(oracle):
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    k = 31
+    rng = np.random.default_rng(3)
+    reads = ["A" * 200] * 50 + rand_reads(rng, 300, 80, 160)
+    st = ReadStream.from_strings(reads)
+    t, (lo, hi, cnt) = oracle_sorted(oracle, k, reads)
+    a_idx = int(np.flatnonzero((lo == 0) & (hi == 0))[0])
+    n_a = int(cnt[a_idx])
+    other = (a_idx + 1) % len(lo)
+    with KmerEngine(k, capacity_hint=1 << 14) as e:
+        e.set_option("force_path", 3)
+        e.count(ReadStream.from_strings(reads[:1]))            # makes the table minimizer-bucketed
+        pre = np.array([0xFFFFFFFF - n_a + 7, 0xFFFFFFF0], np.uint32)
+        e.add_pairs(np.array([lo[a_idx], lo[other]]), np.zeros(2, np.uint64), pre)
+        e.count(ReadStream.from_strings(reads[1:]))
+        got = e.query(np.array([lo[a_idx], lo[other]]), None)
+        assert int(got[0]) == 0xFFFFFFFF, hex(int(got[0]))
+        assert int(got[1]) == min(0xFFFFFFFF, 0xFFFFFFF0 + int(cnt[other]))
+
+
+def test_superkmer_key_space_slices(oracle):
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    k = 31
+    rng = np.random.default_rng(21)
+    genome = rng.integers(0, 4, 60_000).astype(np.uint8)
+    reads = rand_reads(rng, 1500, 40, 300, genome=genome) + ["A" * 200] * 5
+    st = ReadStream.from_strings(reads)
+    t, (lo, hi, cnt) = oracle_sorted(oracle, k, reads)
+    total_windows = oracle.count_windows(reads, k)
+    for parts in (2, 5):
+        got, windows = {}, 0
+        with KmerEngine(k, capacity_hint=1 << 9) as e:
+            e.set_option("force_path", 3); e.set_option("key_parts", parts)
+            for p in range(parts):
+                e.clear(); e.set_option("key_part", p)
+                e.count(st)
+                glo, ghi, gcnt = e.export_ge(0)
+                windows += e.stats()[2]
+                for a, c in zip(glo.tolist(), gcnt.tolist()):
+                    assert a not in got
+                    got[a] = c
+        assert windows == total_windows
+        assert got == {int(a): int(c) for a, c in zip(lo, cnt)}
+
+
+def test_superkmer_refuses_what_it_cannot_do():
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    from kmer_denovo_filter_amd._native import KdfError
+    for k in (11, 41):
+        with KmerEngine(k, capacity_hint=1 << 12) as e:
+            e.set_option("force_path", 3)
+            with pytest.raises(KdfError):
+                e.count(ReadStream.from_strings(["ACGT" * 30]))
