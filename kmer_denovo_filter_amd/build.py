@@ -16,7 +16,9 @@ _INC = os.path.join(os.path.dirname(_PKG), "include")
 LIB_PATH = os.path.join(_PKG, "libkdf.so")
 
 _SOURCES = [
-    ("kdf_engine.hip", ["--offload-arch=gfx950", "-O3"]),
+    # DPP wave scans for uniform-address atomics with per-lane values: this toolchain's default is an iterative
+    # loop over the active lanes (~8 instructions per lane), which made the bucket kernels scalar-issue bound
+    ("kdf_engine.hip", ["--offload-arch=gfx950", "-O3", "-mllvm", "-amdgpu-atomic-optimizer-strategy=DPP"]),
     ("kdf_sort.hip", ["--offload-arch=gfx950", "-O3"]),
     ("kdf_host.cpp", ["-O2", "-x", "c++"]),          # host only: no device pass
 ]
@@ -33,6 +35,7 @@ def _newer(target: str, deps) -> bool:
 
 def build_native(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "hipcc")
+    extra = os.environ.get("KDF_EXTRA_FLAGS", "").split()      # experiments: -DSK_C_THREADS=512 ...
     deps = [d if os.path.isabs(d) else os.path.join(_CSRC, d) for d in _DEPS]
     objs = []
     for src, flags in _SOURCES:
@@ -41,7 +44,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
         objs.append(o)
         if not force and _newer(o, [s] + deps):
             continue
-        cmd = [hipcc, *flags, "-fPIC", "-std=c++17", f"-I{_INC}", f"-I{_CSRC}", "-c", s, "-o", o]
+        cmd = [hipcc, *flags, *extra, "-fPIC", "-std=c++17", f"-I{_INC}", f"-I{_CSRC}", "-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)

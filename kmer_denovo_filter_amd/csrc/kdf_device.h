@@ -67,7 +67,11 @@ struct KdfTable {
     uint64_t *ovf_lo;
     uint32_t *ovf_cnt;
     uint32_t ovf_log2cap;
-    uint32_t pad_;
+    // Balanced minimizer -> bucket assignment (optional): the coarse bin is the top sk_c1 bits of the spread order
+    // value h, the bucket inside the bin is sk_assign[h] (dealt out by weight, kdf_sk.h sk_assign_kernel); without
+    // the table the bucket is simply the top bits of h.
+    uint32_t sk_c1, sk_c2;
+    const uint16_t *sk_assign;
 };
 
 // Slice of a key from the LOW 16 bits of its hash.  (The multi-GPU owner function uses the TOP bits, which are
@@ -92,7 +96,10 @@ __device__ __forceinline__ uint64_t kdf_home(const KdfTable &t, uint64_t h) {
 
 // ---- minimizer-bucketed layout ------------------------------------------------
 #define KDF_SK_M        12                  // minimizer length: 24-bit canonical m-mers
-#define KDF_SK_MAXPROBE 64u                 // slots of a bucket a probe may visit before it turns to the overflow table
+#ifndef KDF_SK_MAXPROBE
+#define KDF_SK_MAXPROBE 64u
+#endif
+//                // slots of a bucket a probe may visit before it turns to the overflow table
 // ORDER of the minimizer scheme: an injective 24-bit scramble (odd multiply mod 2^24, xor-shift) of the canonical
 // m-mer code.  Its top bits name the bucket, so they must be well mixed; one full-rate v_mul_u32_u24.
 __host__ __device__ __forceinline__ uint32_t kdf_sk_order(uint32_t cm) {
@@ -112,15 +119,35 @@ __host__ __device__ __forceinline__ uint32_t kdf_sk_min_of_key(uint64_t x, int k
     }
     return g;
 }
-// bucket of an order value: its top bits (nb_bits = log2cap - bucket_bits <= 24)
+// Minimizers are MINIMA of the order: their order values crowd towards 0 (the smallest of 20 uniform values has
+// mean 2^24 / 21), so the bucket cannot be taken from the order value's own top bits.  A second 24-bit bijection
+// (two odd multiplies mod 2^24 around an xor-shift) spreads them; the bucket is the top bits of THAT.
+__host__ __device__ __forceinline__ uint32_t kdf_sk_spread(uint32_t g) {
+    uint32_t h = (g * 0x6A5D39u) & 0xFFFFFFu;
+    h ^= h >> 13;
+    return (h * 0xC2B2AFu) & 0xFFFFFFu;
+}
+// bucket of an order value: the top bits of its spread (nb_bits = log2cap - bucket_bits <= 24)
 __host__ __device__ __forceinline__ uint32_t kdf_sk_bucket_of(uint32_t g, uint32_t nb_bits) {
-    return nb_bits ? (g >> (24 - nb_bits)) : 0u;
+    return nb_bits ? (kdf_sk_spread(g) >> (24 - nb_bits)) : 0u;
+}
+// slot of a key inside its bucket (SK layout): two 32-bit multiplies; only the top bucket_bits bits are used
+__host__ __device__ __forceinline__ uint32_t kdf_sk_slot(uint64_t key, uint32_t bucket_bits) {
+    uint32_t h = (uint32_t)key * 0x9E3779B1u ^ (uint32_t)(key >> 32) * 0x85EBCA77u;
+    h ^= h >> 15;
+    return (h * 0x2C1B3C6Du) >> (32 - bucket_bits);
+}
+// bucket of an order value in table t
+__device__ __forceinline__ uint32_t kdf_sk_bucket(const KdfTable &t, uint32_t g) {
+    const uint32_t nb_bits = t.log2cap - t.bucket_bits;
+    if (!t.sk_assign) return kdf_sk_bucket_of(g, nb_bits);
+    const uint32_t h = kdf_sk_spread(g);
+    return ((t.sk_c1 ? (h >> (24 - t.sk_c1)) : 0u) << t.sk_c2) | t.sk_assign[h];
 }
 // first slot of key's probe sequence in an SK table
 __device__ __forceinline__ uint64_t kdf_sk_home(const KdfTable &t, uint64_t key) {
-    const uint32_t nb_bits = t.log2cap - t.bucket_bits;
-    const uint64_t b = kdf_sk_bucket_of(kdf_sk_min_of_key(key, (int)t.k), nb_bits);
-    return (b << t.bucket_bits) | (kdf_mix64(key) >> (64 - t.bucket_bits));
+    const uint64_t b = kdf_sk_bucket(t, kdf_sk_min_of_key(key, (int)t.k));
+    return (b << t.bucket_bits) | kdf_sk_slot(key, t.bucket_bits);
 }
 
 __device__ __forceinline__ void kdf_sat_add(uint32_t *p, uint32_t add) {

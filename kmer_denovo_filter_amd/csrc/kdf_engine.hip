@@ -264,7 +264,8 @@ struct kdf_engine {
                                                      // < 2^32 to any slot (kernel C saturates by comparing with the HBM count)
     uint32_t opt_binned_filtered_min_log2cap = 23;   // count --if goes binned from 2^23 slots (measured crossover)
     int opt_force_path = 0;                          // 0 auto, 1 direct, 2 binned, 3 super-k-mer (kdf_sk.h)
-    uint32_t opt_sk_min_k = 20;                      // auto: narrow keys from this k on take the super-k-mer path
+    uint32_t opt_sk_min_k = 20;                      // auto (option sk_auto): narrow keys from this k on take the super-k-mer path
+    int opt_sk_auto = 0;                             // 0: the super-k-mer path only when forced (it is at parity with the binned path)
     // super-k-mer path (kdf_sk.h): scratch, device counters + pinned mirror, overflow table bookkeeping
     void *sk_buf[16] = {nullptr};
     size_t sk_bytes[16] = {0};
@@ -272,6 +273,10 @@ struct kdf_engine {
     uint64_t ovf_used_ub = 0;                        // upper bound of the keys in the overflow table
     bool ovf_dirty = false;                          // overflow arrays hold entries of an earlier table generation
     bool sk_attrs_set[64] = {false};
+    uint16_t *sk_assign = nullptr;                   // balanced minimizer -> bucket table (2^24 entries) of geometry (c1, c2) ...
+    uint32_t *sk_weights = nullptr;                  // ... and the weights it was dealt from
+    uint32_t sk_assign_c1 = 0, sk_assign_c2 = 0;     // 0 / 0: no table yet
+    int opt_sk_balance = 1;
     uint64_t stat_sk_passes = 0, stat_sk_spills = 0, stat_sk_failed = 0, stat_sk_fallbacks = 0;
     int last_path = 0;                               // count path of the last count call: 0 direct, 1 binned, 2 super-k-mer
     uint32_t opt_debug_flags = 0;                    // experiments only (KbPlan::dbg)
@@ -733,7 +738,8 @@ static SkPlan sk_make_plan(const KdfTable &t, int k) {
 static int sk_enter(kdf_engine *h) {
     if (h->t.sk) return KDF_OK;
     h->t.sk = 1; h->t.k = (uint32_t)h->k;
-    h->t.bucket_bits = std::min<uint32_t>(h->t.log2cap, 11);
+    h->t.sk_assign = nullptr; h->t.sk_c1 = h->t.sk_c2 = 0;
+    h->t.bucket_bits = std::min<uint32_t>(h->t.log2cap, SK_BUCKET_BITS);
     h->ovf_used_ub = 0;
     int rc = ovf_alloc(h, h->t, h->t.ovf_lo ? h->t.ovf_log2cap : 16);
     h->ovf_dirty = false;
@@ -741,10 +747,29 @@ static int sk_enter(kdf_engine *h) {
 }
 static void sk_leave(kdf_engine *h) {                  // back to the hash layout (the table must be logically empty)
     if (!h->t.sk) return;
-    h->t.sk = 0;
+    h->t.sk = 0; h->t.sk_assign = nullptr; h->t.sk_c1 = h->t.sk_c2 = 0;
     h->t.bucket_bits = std::min<uint32_t>(h->t.log2cap, 12);
     h->ovf_used_ub = 0; h->ovf_dirty = true;
 }
+
+
+// the balanced minimizer -> bucket table for geometry (c1, c2), from weights already accumulated in h->sk_weights
+static int sk_assign_alloc(kdf_engine *h) {
+    if (!h->sk_assign) HIPCHK(h, hipMalloc((void **)&h->sk_assign, (size_t)(1u << 24) * 2));
+    if (!h->sk_weights) HIPCHK(h, hipMalloc((void **)&h->sk_weights, (size_t)(1u << 24) * 4));
+    return KDF_OK;
+}
+static int sk_assign_deal(kdf_engine *h, uint32_t c1, uint32_t c2) {
+    if (!h->sk_attrs_set[1]) {
+        HIPCHK(h, hipFuncSetAttribute((const void *)sk_assign_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+        h->sk_attrs_set[1] = true;
+    }
+    hipLaunchKernelGGL(sk_assign_kernel, dim3(1u << c1), dim3(1024), 16384 * 8, h->stream, (const uint32_t *)h->sk_weights, h->sk_assign, c1, c2);
+    HIPCHK(h, hipGetLastError());
+    h->sk_assign_c1 = c1; h->sk_assign_c2 = c2;
+    return KDF_OK;
+}
+static bool sk_want_assign(const kdf_engine *h, const SkPlan &p) { return h->opt_sk_balance && p.c1 >= 7 && p.sub_bits == 0; }
 
 template <int K>
 static int sk_launch_extract(kdf_engine *h, unsigned grid, size_t lds, const uint64_t *d_packed, const uint64_t *d_invalid,
@@ -817,15 +842,16 @@ static int sk_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     HIPCHK(h, hipMemsetAsync(h->sk_ctrs, 0, SKC_N * 4, h->stream));
     HIPCHK(h, hipMemsetAsync(s.bin_nchunks, 0, small_words * 4, h->stream));
     HIPCHK(h, hipMemsetAsync(s.failed, 0, failed_bytes, h->stream));
+    HIPCHK(h, hipMemsetAsync(s.sp_cnt, 0, (size_t)s.sp_cap * 4, h->stream));      // a zero count marks a hole in the spill list
 
-    const size_t lds_s1 = (size_t)SK_WPT * SK_THREADS * 4 + (size_t)SK_CAP * 20 + (size_t)(4 * (1 << SK_C1_MAX) + 2 + 40) * 4 + (size_t)(2 * SK_THREADS + 4) * 2 + 16;
+    const size_t lds_s1 = (size_t)SK_WPT * SK_THREADS * 4 + (size_t)SK_CAP * 20 + (size_t)(5 * (1 << SK_C1_MAX) + 2 + 40) * 4 + (size_t)(SK_WP + SK_WM) * 8
+                          + (size_t)(2 * SK_THREADS + 4) * 2 + 16;
     const size_t lds_s2 = (size_t)SK_GREC * 16 + (size_t)(2 * (1 << SK_C2_MAX) + 40 + 2 * SK_GROUP) * 4;
-    const size_t B = (size_t)1 << plan.bucket_bits;
-    const size_t lds_s3 = B * 12 + (size_t)SK_C_RC * 18 + (size_t)SK_C_SQ * 12 + 16 + (size_t)SK_C_DT * 4 + (size_t)(2 * SK_C_RUNS + 1 + 40 + 8) * 4 + 16;
+    const size_t lds_s3 = sk_bucket_lds(plan.bucket_bits);
     if (!h->sk_attrs_set[0]) {
         HIPCHK(h, hipFuncSetAttribute((const void *)sk_finesort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s2));
-        HIPCHK(h, hipFuncSetAttribute((const void *)sk_bucket_kernel<SK_MODE_COUNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(12 * 2048 + lds_s3 - B * 12)));
-        HIPCHK(h, hipFuncSetAttribute((const void *)sk_bucket_kernel<SK_MODE_REPLAY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(12 * 2048 + lds_s3 - B * 12)));
+        HIPCHK(h, hipFuncSetAttribute((const void *)sk_bucket_kernel<SK_MODE_COUNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sk_bucket_lds(12)));
+        HIPCHK(h, hipFuncSetAttribute((const void *)sk_bucket_kernel<SK_MODE_REPLAY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sk_bucket_lds(12)));
         h->sk_attrs_set[0] = true;
     }
 
@@ -842,6 +868,19 @@ static int sk_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
         default: rc = fail(h, KDF_ERR_INVALID, "super-k-mer path: k=%d outside %d..32", h->k, SK_MIN_K);
     }
     if (rc) return rc;
+    if (h->distinct == 0 && h->ovf_used_ub == 0 && !h->t.sk_assign && sk_want_assign(h, plan)) {
+        // first pass of a table generation: fix the minimizer -> bucket assignment.  A table of this geometry dealt
+        // earlier (an engine that is cleared and refilled) is simply used again; else it is dealt from the weights
+        // of this batch's records (a sample of the chunks S1 has just written).
+        if (!(h->sk_assign && h->sk_assign_c1 == plan.c1 && h->sk_assign_c2 == plan.c2)) {
+            if ((rc = sk_assign_alloc(h))) return rc;
+            HIPCHK(h, hipMemsetAsync(h->sk_weights, 0, (size_t)(1u << 24) * 4, h->stream));
+            hipLaunchKernelGGL(sk_weight_records_kernel, dim3((unsigned)max_chunks64), dim3(256), 0, h->stream, s, h->sk_weights);
+            if ((rc = sk_assign_deal(h, plan.c1, plan.c2))) return rc;
+        }
+        h->t.sk_assign = h->sk_assign; h->t.sk_c1 = plan.c1; h->t.sk_c2 = plan.c2;
+    }
+    plan.assign = h->t.sk_assign;
     stamp();                                                   // end of S1
     hipLaunchKernelGGL(sk_binscan_kernel, dim3(1), dim3(1024), 0, h->stream, plan, s);
     hipLaunchKernelGGL(sk_chunklist_kernel, dim3((unsigned)((max_chunks64 + 255) / 256)), dim3(256), 0, h->stream, s);
@@ -862,6 +901,7 @@ static int sk_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     bool full = false;
     if ((rc = ctl_sync(h, &full))) return rc;
     const uint32_t *c = h->sk_ctrs_host;
+    for (int i = 0; i < 6; ++i) h->stat_dbg[i] = c[8 + i];
     if (c[SKC_EXHAUSTED]) { h->stat_sk_fallbacks++; return SK_RC_EXHAUSTED; }          // nothing was inserted
     h->stat_sk_passes++;
     h->lazy_empty = false;
@@ -927,7 +967,7 @@ static bool use_sk(const kdf_engine *h, uint64_t n_bases) {
     if (h->filter_mode || h->distinct != 0) return false;       // layouts change only on an empty table
     if (h->opt_force_path == 3) return true;
     if (h->opt_force_path != 0) return false;
-    return (uint32_t)h->k >= h->opt_sk_min_k && n_bases >= h->opt_binned_min_positions;
+    return h->opt_sk_auto && (uint32_t)h->k >= h->opt_sk_min_k && n_bases >= h->opt_binned_min_positions;
 }
 
 
@@ -968,10 +1008,27 @@ static int sk_table_rehash(kdf_engine *h, uint32_t new_log2) {
     KdfTable nt;
     rc = table_alloc(h, new_log2, nt);
     if (rc) { table_free(nt); return rc; }
-    nt.sk = 1; nt.k = (uint32_t)h->k; nt.bucket_bits = std::min<uint32_t>(new_log2, 11);
+    nt.sk = 1; nt.k = (uint32_t)h->k; nt.bucket_bits = std::min<uint32_t>(new_log2, SK_BUCKET_BITS);
     nt.key_parts = h->opt_key_parts; nt.key_part = h->opt_key_part;
     if ((rc = ovf_alloc(h, nt, std::max<uint32_t>(16, h->t.ovf_lo ? h->t.ovf_log2cap : 16)))) { table_free(nt); return rc; }
+    nt.sk_assign = nullptr; nt.sk_c1 = nt.sk_c2 = 0;
     KdfTable old = h->t;
+    {
+        const SkPlan np = sk_make_plan(nt, h->k);
+        if (n_keys && sk_want_assign(h, np)) {
+            // the new geometry's assignment is dealt from the exact weights: one per key the old table holds
+            if ((rc = sk_assign_alloc(h))) { table_free(nt); return rc; }
+            HIPCHK(h, hipMemsetAsync(h->sk_weights, 0, (size_t)(1u << 24) * 4, h->stream));
+            const uint64_t oc = 1ull << old.log2cap;
+            hipLaunchKernelGGL(sk_weight_table_kernel, dim3((unsigned)((oc + 255) / 256)), dim3(256), 0, h->stream, (const uint64_t *)old.lo, oc, h->k, h->sk_weights);
+            if (old.ovf_lo && h->ovf_used_ub) {
+                const uint64_t vc = 1ull << old.ovf_log2cap;
+                hipLaunchKernelGGL(sk_weight_table_kernel, dim3((unsigned)((vc + 255) / 256)), dim3(256), 0, h->stream, (const uint64_t *)old.ovf_lo, vc, h->k, h->sk_weights);
+            }
+            if ((rc = sk_assign_deal(h, np.c1, np.c2))) { table_free(nt); return rc; }
+            nt.sk_assign = h->sk_assign; nt.sk_c1 = np.c1; nt.sk_c2 = np.c2;
+        }
+    }
     h->t = nt; h->cap = 1ull << new_log2;
     const uint64_t old_ovf_used = h->ovf_used_ub;
     h->ovf_used_ub = 0;
@@ -1136,6 +1193,8 @@ void kdf_destroy(kdf_engine *h) {
     for (int i = 0; i < 4; ++i) if (h->stage[i]) (void)hipFree(h->stage[i]);
     for (int i = 0; i < 6; ++i) if (h->kb_buf[i]) (void)hipFree(h->kb_buf[i]);
     for (int i = 0; i < 16; ++i) if (h->sk_buf[i]) (void)hipFree(h->sk_buf[i]);
+    if (h->sk_assign) (void)hipFree(h->sk_assign);
+    if (h->sk_weights) (void)hipFree(h->sk_weights);
     if (h->sk_ctrs) (void)hipFree(h->sk_ctrs);
     if (h->sk_ctrs_host) (void)hipHostFree(h->sk_ctrs_host);
     if (h->kb_small) (void)hipFree(h->kb_small);
@@ -1650,6 +1709,8 @@ int kdf_set_option(kdf_engine *h, const char *name, int64_t value) {
     else if (n == "binned_filtered_min_log2cap") h->opt_binned_filtered_min_log2cap = (uint32_t)value;
     else if (n == "force_path") h->opt_force_path = (int)value;
     else if (n == "sk_min_k") h->opt_sk_min_k = (uint32_t)value;
+    else if (n == "sk_balance") h->opt_sk_balance = (int)value;
+    else if (n == "sk_auto") h->opt_sk_auto = (int)value;
     else if (n == "debug_flags") h->opt_debug_flags = (uint32_t)value;
     else return fail(h, KDF_ERR_INVALID, "kdf_set_option: unknown option %s", name);
     return KDF_OK;
@@ -1665,7 +1726,7 @@ int kdf_get_stat(kdf_engine *h, const char *name, int64_t *value) {
     else if (n == "sk_spills") *value = (int64_t)h->stat_sk_spills;
     else if (n == "sk_failed_buckets") *value = (int64_t)h->stat_sk_failed;
     else if (n == "sk_fallbacks") *value = (int64_t)h->stat_sk_fallbacks;
-    else if (n == "layout") *value = h->t.sk ? 1 : 0;
+    else if (n == "layout") *value = h->t.sk ? (h->t.sk_assign ? 2 : 1) : 0;
     else if (n == "last_count_path") *value = h->last_path;
     else if (n == "ovf_log2cap") *value = h->t.ovf_lo ? (int64_t)h->t.ovf_log2cap : 0;
     else if (n == "log2cap") *value = h->t.log2cap;

@@ -34,15 +34,28 @@
 #define SK_GROUP     32                    // chunks per S2 group
 #define SK_GREC      (SK_CHUNK * SK_GROUP) // 8192 records: 128 KB of LDS
 #define SK_NONE      0xFFFFFFFFu
+#define SK_WP        (SK_SLAB / 32 + 6)    // packed words one slab's threads read: one before the slab, up to 52 bases past it
+#define SK_WM        (SK_SLAB / 64 + 4)
 #define SK_MIN_K     16
 // bucket kernel
 #ifndef SK_C_THREADS
 #define SK_C_THREADS 256
 #endif
-#define SK_C_RC      1024                  // records per dedupe round
+#ifndef SK_C_RC
+#define SK_C_RC      512                   // records per dedupe round (a 2048-slot bucket of the bench holds ~470)
+#endif
 #define SK_C_DT      1024                  // dedupe hash slots
-#define SK_C_RUNS    SK_C_THREADS          // runs (groups of the bin) staged per round: one per thread
-#define SK_C_SQ      128                   // LDS spill queue entries
+#ifndef SK_C_IC
+#define SK_C_IC      3072                  // (record, k-mer) items of the flat expansion list per round
+#endif
+#ifndef SK_BUCKET_BITS
+#define SK_BUCKET_BITS 11                  // slots per bucket of an SK-layout table (2^11: three 256-thread bucket workgroups per CU)
+#endif
+#ifndef SK_C_WQ
+#define SK_C_WQ      96                    // per wave: keys whose probe goes past the two slots read up front
+#endif
+#define SK_C_RUNS    256                   // runs (groups of the bin) staged per round: one per thread (SK_C_THREADS >= 256)
+#define SK_C_SQ      64                    // LDS spill queue entries
 #define SK_C_DPROBE  32                    // dedupe probes before a record is expanded on its own
 
 struct __attribute__((aligned(16))) SkRec { uint64_t lo, hi; };
@@ -67,6 +80,7 @@ struct SkPlan {
     uint32_t k;
     uint32_t goff_stride;                 // 2^c2 + 1
     uint32_t dbg;
+    const uint16_t *assign;               // balanced bucket-in-bin table indexed by the spread order value, or null
 };
 
 enum { SKC_POOL = 0, SKC_EXHAUSTED = 1, SKC_GROUPS = 2, SKC_SPILL = 3, SKC_FAILED = 4, SKC_BADNK = 5, SKC_SPILL_LOST = 6, SKC_N = 16 };
@@ -104,18 +118,19 @@ __device__ __forceinline__ uint64_t sk_shr128(uint64_t a, uint64_t b, int sh) { 
 // Out: mv[i] = (order value << 8 | m-mer index in the span) of the minimizer of window P - 1 + i, i = 0..16, and
 // bit i of v17 = window P - 1 + i is valid.  The span starts at S = P - 1; for P = 0 a virtual invalid base stands
 // at position -1.
+// `packed` / `invalid` are (LDS) copies of the stream words from word index pw0 / mw0 on.
 template <int K>
-__device__ __forceinline__ void sk_windows(const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid,
+__device__ __forceinline__ void sk_windows(const uint64_t *packed, const uint64_t *invalid, uint64_t pw0, uint64_t mw0,
                                            uint64_t P, uint32_t (&mv)[SK_WPT + 1], uint32_t &v17) {
     using C = SkK<K>;
     constexpr int NM = C::NM, W = C::W, M = C::M;
     uint64_t e0, e1, inv;
     if (P > 0) {
         const uint64_t S = P - 1;
-        const uint64_t w0 = S >> 5; const int sh = (int)(S & 31) * 2;
+        const uint64_t w0 = (S >> 5) - pw0; const int sh = (int)(S & 31) * 2;
         const uint64_t x0 = packed[w0], x1 = packed[w0 + 1], x2 = packed[w0 + 2];
         e0 = kdf_funnel(x0, x1, sh); e1 = kdf_funnel(x1, x2, sh);
-        const uint64_t mw = S >> 6; const int msh = (int)(S & 63);
+        const uint64_t mw = (S >> 6) - mw0; const int msh = (int)(S & 63);
         inv = kdf_funnel(invalid[mw], invalid[mw + 1], msh);
     } else {
         const uint64_t x0 = packed[0], x1 = packed[1];
@@ -177,7 +192,10 @@ __global__ __launch_bounds__(SK_THREADS) void sk_extract_kernel(
     uint32_t *cur_chunk = offs + NBMAX + 1;                                    // [NBMAX]
     uint32_t *cur_fill = cur_chunk + NBMAX;                                    // [NBMAX]
     uint32_t *wsum = cur_fill + NBMAX;                                         // [40]
-    uint16_t *nat = (uint16_t *)(wsum + 40);                                   // [SK_THREADS] natural breaks
+    uint32_t *nxt = wsum + 40;                                                 // [NBMAX] first of the chunks taken for the bin this round
+    uint64_t *wp = (uint64_t *)(nxt + NBMAX);                                  // [SK_WP] the slab's packed words (+ look-back / look-ahead)
+    uint64_t *wm = wp + SK_WP;                                                 // [SK_WM] the slab's mask words
+    uint16_t *nat = (uint16_t *)(wm + SK_WM);                                  // [SK_THREADS] natural breaks
     uint16_t *brk = nat + SK_THREADS;                                          // [SK_THREADS + 4] final breaks
     const int nb = 1 << plan.c1;
     const int tid = threadIdx.x;
@@ -185,19 +203,31 @@ __global__ __launch_bounds__(SK_THREADS) void sk_extract_kernel(
     if (tid < 4) brk[SK_THREADS + tid] = 0xFFFFu;                              // the slab's end is a break
     __syncthreads();
     const uint64_t slab0 = (uint64_t)blockIdx.x * slabs_per_wg;
-    const int half = tid >> 5, lane32 = tid & 31;
-    constexpr int NHALF = SK_THREADS / 32;
+    const int grp16 = tid >> 4, lane16 = tid & 15;
+    constexpr int NGRP = SK_THREADS / 16;
+    const bool stampit = (plan.dbg & 32) && tid == 0;
+    uint64_t st_t = stampit ? __builtin_amdgcn_s_memtime() : 0;
+    uint32_t st_acc[6] = {0, 0, 0, 0, 0, 0};
+#define SK1_STAMP(I) if (stampit) { const uint64_t n_ = __builtin_amdgcn_s_memtime(); st_acc[I] += (uint32_t)((n_ - st_t) >> 4); st_t = n_; }
     for (uint32_t sl = 0; sl < slabs_per_wg; ++sl) {
         const uint64_t P0 = (slab0 + sl) * (uint64_t)SK_SLAB;
         if (P0 >= n_bases) break;                                              // uniform
         const uint64_t P = P0 + (uint64_t)tid * SK_WPT;
+        // the slab's stream words -> LDS (every later read of the stream, the record assembly's included, is an LDS read)
+        const uint64_t pw0 = P0 ? (P0 - 1) >> 5 : 0, mw0 = P0 ? (P0 - 1) >> 6 : 0;
+        {
+            const uint64_t pw_end = ((n_bases + KDF_TILE - 1) / KDF_TILE) * 2 + 4, mw_end = (n_bases + KDF_TILE - 1) / KDF_TILE + 2;   // kdf_stream_words
+            if (tid < SK_WP) wp[tid] = pw0 + tid < pw_end ? packed[pw0 + tid] : 0ull;
+            else if (tid - SK_WP < SK_WM) wm[tid - SK_WP] = mw0 + (tid - SK_WP) < mw_end ? invalid[mw0 + tid - SK_WP] : ~0ull;
+        }
+        __syncthreads();
         uint32_t round = 0, rounds = 1;
         do {
             // ---- windows, minimizers, record boundaries (recomputed per round: rounds > 1 only for pathological slabs)
             uint32_t start16 = 0, brk16 = 0xFFFFu;
             {
                 uint32_t mv[SK_WPT + 1], v17 = 0;
-                if (P < n_bases) sk_windows<K>(packed, invalid, P, mv, v17);
+                if (P < n_bases) sk_windows<K>(wp, wm, pw0, mw0, P, mv, v17);
                 else {
 #pragma unroll
                     for (int i = 0; i <= SK_WPT; ++i) mv[i] = 0;
@@ -230,30 +260,43 @@ __global__ __launch_bounds__(SK_THREADS) void sk_extract_kernel(
                 brk16 = (start16 | ~v16) & 0xFFFFu;
                 brk[tid] = (uint16_t)brk16;
             }
+            SK1_STAMP(0)
             const uint32_t nrec = __popc(start16);
             uint32_t total = 0;
             const uint32_t tbase = kb_block_exscan(nrec, wsum, &total);       // (its barriers publish brk[])
+            SK1_STAMP(1)
             rounds = (total + SK_CAP - 1) / SK_CAP;
             if (rounds == 0) break;
             const uint32_t r_lo = round * SK_CAP;
-            // ---- emission: one record per start bit
+            // ---- emission.  First the starts of this round as a dense list (T[r] = thread << 4 | window), then one
+            // record per LIST ENTRY: the record assembly runs with every lane busy instead of inside a per-thread loop
+            // over start bits (a thread has 1.7 starts on average, a wave's busiest lane 5-6).
             {
-                const uint64_t look = (uint64_t)brk16 | ((uint64_t)brk[tid + 1] << 16) | ((uint64_t)brk[tid + 2] << 32);
-                uint32_t sb = start16, ord = tbase;
+                uint32_t sb = start16, ord = tbase - r_lo;
                 while (sb) {
                     const int i = __ffs(sb) - 1; sb &= sb - 1;
-                    const uint32_t r = ord - r_lo; ++ord;
-                    if (r >= SK_CAP) continue;                                 // another round's record (unsigned wrap: earlier rounds too)
+                    if (ord < SK_CAP) T[ord] = ((uint32_t)tid << 4) | (uint32_t)i;   // (unsigned wrap: earlier rounds' records too)
+                    ++ord;
+                }
+            }
+            kb_lds_barrier();
+            {
+                const uint32_t nr = min((uint32_t)SK_CAP, total - r_lo);
+                for (uint32_t r = tid; r < nr; r += SK_THREADS) {
+                    const uint32_t ti = T[r], t_ = ti >> 4; const int i = (int)(ti & 15u);
+                    const uint64_t look = (uint64_t)brk[t_] | ((uint64_t)brk[t_ + 1] << 16) | ((uint64_t)brk[t_ + 2] << 32);
                     const uint64_t after = look >> (i + 1);
                     const int nk = after ? __ffsll((unsigned long long)after) : 48;
-                    if (nk > C::MAXNK) { s.ctrs[SKC_BADNK] = 1; continue; }  // cannot happen (forced cuts); never silent
-                    const uint32_t mvv = lds_mv[i * SK_THREADS + tid];
+                    if (nk > C::MAXNK) {                                       // cannot happen (forced cuts); never silent: the host fails the pass
+                        s.ctrs[SKC_BADNK] = 1; U[r] = SkRec{0, 0}; T[r] = atomicAdd(&hist[0], 1u); continue;
+                    }
+                    const uint32_t mvv = lds_mv[i * SK_THREADS + t_];
                     const uint32_t g = mvv >> 8;
                     const int off_fw = (int)(mvv & 0xFF) - 1 - i;              // minimizer m-mer offset inside the record
-                    const uint64_t Q = P + i;
+                    const uint64_t Q = P0 + (uint64_t)t_ * SK_WPT + i;
                     const int nbases = nk + K - 1;                             // <= 52
-                    const uint64_t w0 = Q >> 5; const int sh = (int)(Q & 31) * 2;
-                    const uint64_t x0 = packed[w0], x1 = packed[w0 + 1], x2 = packed[w0 + 2];
+                    const uint64_t w0 = (Q >> 5) - pw0; const int sh = (int)(Q & 31) * 2;
+                    const uint64_t x0 = wp[w0], x1 = wp[w0 + 1], x2 = wp[w0 + 2];
                     uint64_t lo = kdf_funnel(x0, x1, sh), hi = kdf_funnel(x1, x2, sh);
                     const int hb = 2 * nbases - 64;                            // bits used in hi
                     const uint64_t hmask = hb > 0 ? ((1ull << hb) - 1) : 0ull;
@@ -267,13 +310,14 @@ __global__ __launch_bounds__(SK_THREADS) void sk_extract_kernel(
                     int off = off_fw;
                     if (chi < hi || (chi == hi && clo < lo)) { lo = clo; hi = chi; off = nbases - KDF_SK_M - off_fw; }
                     hi |= ((uint64_t)(uint32_t)off << 48) | ((uint64_t)(uint32_t)nk << 56);
-                    const uint32_t bin = plan.c1 ? (g >> (24 - plan.c1)) : 0u;
+                    const uint32_t bin = plan.c1 ? (kdf_sk_spread(g) >> (24 - plan.c1)) : 0u;
                     const uint32_t rank = atomicAdd(&hist[bin], 1u);
                     U[r] = SkRec{lo, hi};
                     T[r] = (bin << 16) | rank;
                 }
             }
             kb_lds_barrier();
+            SK1_STAMP(2)
             if (tid < 64) {                                                    // exclusive scan of hist[0..nb) by one wave
                 const int per = (nb + 63) >> 6;
                 const int b0 = tid * per;
@@ -284,8 +328,24 @@ __global__ __launch_bounds__(SK_THREADS) void sk_extract_kernel(
                 for (int o = 1; o < 64; o <<= 1) { uint32_t t_ = __shfl_up(inc, o); if (tid >= o) inc += t_; }
                 uint32_t run = inc - sum;
                 for (int i = 0; i < per; ++i) if (b0 + i < nb) { offs[b0 + i] = run; run += hist[b0 + i]; }
+            } else if (tid - 64 < nb) {
+                // meanwhile a thread per bin takes the chunks its run needs beyond the bin's current chunk: all bins at
+                // once, two independent atomics each, so their latency is paid once per round and not inside the copy-out
+                const int bin = tid - 64;
+                const uint32_t n = hist[bin], ch = cur_chunk[bin];
+                const uint32_t room = ch == SK_NONE ? 0u : (uint32_t)SK_CHUNK - cur_fill[bin];
+                uint32_t id0 = SK_NONE;
+                if (n > room) {
+                    const uint32_t need = (n - room + SK_CHUNK - 1) / SK_CHUNK;
+                    id0 = atomicAdd(&s.ctrs[SKC_POOL], need);
+                    const uint32_t pos0 = atomicAdd(&s.bin_nchunks[bin], need);
+                    if (id0 + need > s.max_chunks || id0 + need < id0) { s.ctrs[SKC_EXHAUSTED] = 1; id0 = SK_NONE - 1; }
+                    else for (uint32_t q = 0; q < need; ++q) { s.chunk_bin[id0 + q] = (uint32_t)bin; s.chunk_pos[id0 + q] = pos0 + q; }
+                }
+                nxt[bin] = id0;
             }
             kb_lds_barrier();
+            SK1_STAMP(3)
             {
                 const uint32_t nr = min((uint32_t)SK_CAP, total - r_lo);
                 for (uint32_t r = tid; r < nr; r += SK_THREADS) {
@@ -294,37 +354,34 @@ __global__ __launch_bounds__(SK_THREADS) void sk_extract_kernel(
                 }
             }
             kb_lds_barrier();
-            // ---- copy-out: a half-wave per bin; the bin's run goes to this workgroup's current chunk of the bin
-            for (int bin = half; bin < nb; bin += NHALF) {
+            SK1_STAMP(4)
+            // ---- copy-out: 16 lanes per bin; the bin's run goes to this workgroup's current chunk of the bin and on
+            // into the chunks taken above (consecutive ids)
+            for (int bin = grp16; bin < nb; bin += NGRP) {
                 const uint32_t n = hist[bin], o = offs[bin];
                 if (n == 0) continue;
-                uint32_t ch = cur_chunk[bin], fl = cur_fill[bin], done = 0;
+                uint32_t ch = cur_chunk[bin], fl = cur_fill[bin], nx = nxt[bin], done = 0;
                 while (done < n) {
                     if (ch == SK_NONE || fl == SK_CHUNK) {
-                        uint32_t nid = 0;
-                        if (lane32 == 0) {
-                            if (ch != SK_NONE && ch < s.max_chunks) s.chunk_fill[ch] = SK_CHUNK;
-                            nid = atomicAdd(&s.ctrs[SKC_POOL], 1u);
-                            if (nid < s.max_chunks) {
-                                s.chunk_bin[nid] = (uint32_t)bin;
-                                s.chunk_pos[nid] = atomicAdd(&s.bin_nchunks[bin], 1u);
-                            } else s.ctrs[SKC_EXHAUSTED] = 1;
-                        }
-                        ch = __shfl(nid, 0, 32); fl = 0;
+                        if (lane16 == 0 && ch != SK_NONE && ch < s.max_chunks) s.chunk_fill[ch] = SK_CHUNK;
+                        ch = nx; fl = 0;
+                        if (nx < SK_NONE - 1) ++nx;                            // (SK_NONE - 1: the pool ran out, nothing is written)
                     }
                     const uint32_t take = min(n - done, (uint32_t)SK_CHUNK - fl);
                     if (ch < s.max_chunks) {
                         SkRec *dst = s.chunks + (size_t)ch * SK_CHUNK + fl;
-                        for (uint32_t i = lane32; i < take; i += 32) dst[i] = img[o + done + i];
+                        for (uint32_t i = lane16; i < take; i += 16) dst[i] = img[o + done + i];
                     }
                     done += take; fl += take;
                 }
-                if (lane32 == 0) { cur_chunk[bin] = ch; cur_fill[bin] = fl; hist[bin] = 0; }
+                if (lane16 == 0) { cur_chunk[bin] = ch; cur_fill[bin] = fl; hist[bin] = 0; }
             }
             kb_lds_barrier();
+            SK1_STAMP(5)
             ++round;
         } while (round < rounds);
     }
+    if (stampit) for (int i = 0; i < 6; ++i) atomicAdd(&s.ctrs[8 + i], st_acc[i] >> 6);
     for (int i = tid; i < nb; i += SK_THREADS) {
         const uint32_t ch = cur_chunk[i];
         if (ch != SK_NONE && ch < s.max_chunks) s.chunk_fill[ch] = cur_fill[i];
@@ -402,8 +459,8 @@ __global__ __launch_bounds__(SK_THREADS) void sk_finesort_kernel(SkPlan plan, Sk
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         if (br[e] != SK_NONE) {
-            const uint32_t g = sk_rec_order(rl[e], rh[e]);
-            const uint32_t f = plan.c2 ? ((g >> (24 - plan.c1 - plan.c2)) & ((1u << plan.c2) - 1)) : 0u;
+            const uint32_t g = kdf_sk_spread(sk_rec_order(rl[e], rh[e]));
+            const uint32_t f = plan.assign ? (uint32_t)plan.assign[g] : plan.c2 ? ((g >> (24 - plan.c1 - plan.c2)) & ((1u << plan.c2) - 1)) : 0u;
             br[e] = (f << 16) | atomicAdd(&hist[f], 1u);
         }
     }
@@ -439,6 +496,31 @@ __device__ __forceinline__ uint32_t sk_rec_hash(uint64_t lo, uint64_t hi) {
     return h ^ (h >> 15);
 }
 
+// LDS bytes of the bucket kernel for 2^bucket_bits slots
+__host__ __device__ constexpr size_t sk_bucket_lds(uint32_t bucket_bits) {
+    static_assert(SK_C_THREADS >= SK_C_RUNS && SK_C_THREADS % 64 == 0 && SK_C_RC <= 1024 && SK_C_IC % 4 == 0 && SK_C_WQ % 4 == 0, "bucket kernel geometry");
+    return ((size_t)12 << bucket_bits) + (size_t)SK_C_RC * 16 + (size_t)SK_C_SQ * 12 + 16 + (size_t)SK_C_DT * 4
+           + (size_t)(2 * SK_C_RUNS + 2 + 40 + 8) * 4 + (size_t)SK_C_IC * 2 + (size_t)(SK_C_THREADS / 64) * SK_C_WQ * 14 + (size_t)SK_C_RC * 2 + 16;
+}
+
+// one key into the LDS slice, starting from a slot value read earlier (`cur` may be stale: a slot read as EMPTY may
+// have been taken since -- the CAS tells -- and a slot read as taken stays taken).  false: the key's neighbourhood
+// of KDF_SK_MAXPROBE slots holds neither the key nor room.
+__device__ __forceinline__ bool sk_slice_add(uint64_t *tlo, uint32_t *tcnt, uint32_t bmask, uint32_t lim, uint64_t key, uint32_t mult,
+                                             uint32_t sl, uint64_t cur, uint32_t &claimed, uint32_t n = 0) {
+    if (n >= lim) return false;
+    for (;;) {
+        if (cur == KDF_EMPTY) {
+            cur = atomicCAS((unsigned long long *)&tlo[sl], KDF_EMPTY, key);
+            if (cur == KDF_EMPTY) { ++claimed; cur = key; }
+        }
+        if (cur == key) { atomicAdd(&tcnt[sl], mult); return true; }
+        if (++n >= lim) return false;
+        sl = (sl + 1) & bmask;
+        cur = tlo[sl];
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(SK_C_THREADS) void sk_bucket_kernel(SkPlan plan, SkScratch s, KdfTable t, KdfCtl *ctl, int table_nonempty)
 {
@@ -452,13 +534,21 @@ __global__ __launch_bounds__(SK_C_THREADS) void sk_bucket_kernel(SkPlan plan, Sk
     uint32_t *tcnt = (uint32_t *)(w64 + 2);                                    // [B]
     uint32_t *own = tcnt + B;                                                  // [DT] multiplicity << 16 | representative
     uint32_t *sqc = own + SK_C_DT;                                             // [SQ]
-    uint32_t *run_pref = sqc + SK_C_SQ;                                        // [RUNS + 1]
-    uint32_t *run_first = run_pref + SK_C_RUNS + 1;                            // [RUNS]
+    uint32_t *run_pref = sqc + SK_C_SQ;                                        // [RUNS + 2]
+    uint32_t *run_first = run_pref + SK_C_RUNS + 2;                            // [RUNS]
     uint32_t *wsum = run_first + SK_C_RUNS;                                    // [40]
-    uint32_t *sh = wsum + 40;                                                  // [8] n_dl, n_sq, failed, claimed, sp_base
-    uint16_t *dl = (uint16_t *)(sh + 8);                                       // [RC] distinct list
+    uint32_t *sh = wsum + 40;                                                  // [8] n_items, n_sq, failed, claimed, sp_base
+    uint16_t *items = (uint16_t *)(sh + 8);                                    // [IC] representative record << 5 | k-mer index (0xFFFF: none)
+    uint16_t *qs = items + SK_C_IC;                                            // [waves][WQ] slot a queued key goes on from
+    uint32_t *qm = (uint32_t *)(qs + (CT / 64) * SK_C_WQ);                     // [waves][WQ] its multiplicity
+    uint64_t *qk = (uint64_t *)(qm + (CT / 64) * SK_C_WQ);                     // [waves][WQ] the key (IC, WQ even: 8-byte aligned)
+    uint16_t *mr = (uint16_t *)(qk + (CT / 64) * SK_C_WQ);                     // [RC] multiplicity of the record (representatives only)
 
     const uint32_t nbk = gridDim.x, tid = threadIdx.x;
+    const bool stampit = (plan.dbg & 16) && tid == 0 && (blockIdx.x & 63) == 0;
+    uint64_t st_t = stampit ? __builtin_amdgcn_s_memtime() : 0;
+    uint32_t st_acc[6] = {0, 0, 0, 0, 0, 0};
+#define SK_STAMP(I) if (stampit) { const uint64_t n_ = __builtin_amdgcn_s_memtime(); st_acc[I] += (uint32_t)(n_ - st_t); st_t = n_; }
     // an XCD takes a contiguous eighth of the buckets (neighbouring buckets share the lines of the offset tables)
     const uint64_t bucket = (nbk & 7) ? blockIdx.x : (uint64_t)(blockIdx.x & 7) * (nbk >> 3) + (blockIdx.x >> 3);
     if (s.ctrs[SKC_EXHAUSTED]) return;                                         // S1 ran out of chunks: nothing may be inserted
@@ -478,12 +568,36 @@ __global__ __launch_bounds__(SK_C_THREADS) void sk_bucket_kernel(SkPlan plan, Sk
         for (uint32_t i = tid; i < B / 2; i += CT) { ((ulonglong2 *)tlo)[i] = e2; ((uint2 *)tcnt)[i] = uint2{0u, 0u}; }
     }
     __syncthreads();
+    SK_STAMP(0)
 
     const int k = (int)plan.k;
     const uint64_t kmask = (k >= 32) ? ~0ull : ((1ull << (2 * k)) - 1);
     const bool sliced = plan.key_parts > 1;
     const uint32_t nb_bits = plan.log2cap - plan.bucket_bits;
+    const uint32_t lim = B < KDF_SK_MAXPROBE ? B : KDF_SK_MAXPROBE;
     uint32_t claimed = 0; unsigned long long nwin = 0; bool failed = false;
+    // one key that found no room: queue it for the overflow table
+    auto spill = [&](uint64_t key, uint32_t mult) {
+        if constexpr (MODE == SK_MODE_REPLAY) {
+            const uint32_t p = atomicAdd(&s.ctrs[SKC_SPILL], 1u);
+            if (p < s.sp_cap) { s.sp_key[p] = key; s.sp_cnt[p] = mult; }
+            else s.ctrs[SKC_SPILL_LOST] = 1;                                   // host sized the list for the worst case: never taken
+        } else {
+            const uint32_t q = atomicAdd(&sh[1], 1u);
+            if (q < SK_C_SQ) { sqk[q] = key; sqc[q] = mult; }
+            else failed = true;
+        }
+    };
+    // k-mer j of the record an item names -> (key, multiplicity, first slot); false: not this slice's / not this table bucket's
+    auto item_key = [&](uint32_t it, uint64_t &key, uint32_t &mult, uint32_t &sl) -> bool {
+        const uint32_t j = it & 31u, r = it >> 5;
+        mult = mr[r];
+        const uint64_t lo = rlo[r], hb = rhi[r] & SK_HI_BASES;
+        key = kdf_canon_narrow(kdf_funnel(lo, hb, 2 * (int)j), k, kmask);
+        sl = kdf_sk_slot(key, plan.bucket_bits);
+        return !(sliced && kdf_slice(kdf_mix64(key), plan.key_parts) != plan.key_part);
+    };
+
     const uint32_t g0 = s.group_first[bin], g1 = s.group_first[bin + 1];
     for (uint32_t gb = g0; gb < g1; gb += SK_C_RUNS) {
         const uint32_t nruns = min((uint32_t)SK_C_RUNS, g1 - gb);
@@ -501,81 +615,134 @@ __global__ __launch_bounds__(SK_C_THREADS) void sk_bucket_kernel(SkPlan plan, Sk
             if (tid == 0) run_pref[SK_C_RUNS] = tot;
             __syncthreads();
         }
+        SK_STAMP(1)
         const uint32_t total = run_pref[SK_C_RUNS];
         for (uint32_t rb = 0; rb < total; rb += SK_C_RC) {
             const uint32_t nrec = min((uint32_t)SK_C_RC, total - rb);
-            // ---- this round's records -> LDS
-            for (uint32_t i = tid; i < nrec; i += CT) {
-                const uint32_t flat = rb + i;
-                uint32_t lo_ = 0, hi_ = nruns;                                 // largest run with run_pref[run] <= flat
-                while (hi_ - lo_ > 1) { const uint32_t mid = (lo_ + hi_) >> 1; if (run_pref[mid] <= flat) lo_ = mid; else hi_ = mid; }
-                const SkRec v = s.sorted[(size_t)run_first[lo_] + (flat - run_pref[lo_])];
-                rlo[i] = v.lo; rhi[i] = v.hi;
+            // ---- this round's records -> LDS: eight lanes per run (a run holds ~8 records), no search
+            for (uint32_t r0 = 0; r0 < nruns; r0 += CT / 8) {
+                const uint32_t r = r0 + (tid >> 3);
+                if (r < nruns) {
+                    const uint32_t a = run_pref[r], b = run_pref[r + 1 < nruns ? r + 1 : SK_C_RUNS];
+                    const uint32_t lo_ = a > rb ? a : rb, hi_ = b < rb + SK_C_RC ? b : rb + SK_C_RC;       // the part of the run in this round
+                    const uint32_t first = run_first[r];
+                    for (uint32_t i = lo_ + (tid & 7); i < hi_; i += 8) {
+                        const SkRec v = s.sorted[(size_t)first + (i - a)];
+                        rlo[i - rb] = v.lo; rhi[i - rb] = v.hi;
+                    }
+                }
             }
+            for (uint32_t i = tid; i < SK_C_RC / 2; i += CT) ((uint32_t *)mr)[i] = 0u;
             for (uint32_t i = tid; i < SK_C_DT; i += CT) own[i] = EMPTY32;
             if (tid == 0) sh[0] = 0;
             __syncthreads();
-            // ---- merge identical records: a CAS names the slot's representative, later copies add to its multiplicity
-            for (uint32_t i = tid; i < nrec; i += CT) {
+            SK_STAMP(2)
+            // ---- merge identical records: a CAS names the slot's representative, later copies add to its multiplicity.
+            // The winner (and a record that found no dedupe slot) appends one ITEM per k-mer to the flat work list.
+            uint32_t pend_ent[(SK_C_RC + CT - 1) / CT], pend_n = 0;             // records whose items did not fit the list
+            for (uint32_t i = tid; i < nrec && !(plan.dbg & 128); i += CT) {
                 const uint64_t ml = rlo[i], mh = rhi[i];
                 if (plan.sub_bits && kdf_sk_bucket_of(sk_rec_order(ml, mh), nb_bits) != (uint32_t)bucket) continue;   // sibling bucket's record
                 uint32_t hs = sk_rec_hash(ml, mh) & (SK_C_DT - 1);
-                uint32_t entry = 0x8000u | i;                                  // default: expanded on its own
-                bool append = true;
+                uint32_t rep = i;                                              // default (no dedupe slot found): expanded on its own
                 for (uint32_t n = 0; n < SK_C_DPROBE; ++n) {
                     uint32_t o = own[hs];
                     if (o == EMPTY32) {
-                        o = atomicCAS(&own[hs], EMPTY32, (1u << 16) | i);
-                        if (o == EMPTY32) { entry = hs; break; }
+                        o = atomicCAS(&own[hs], EMPTY32, i);
+                        if (o == EMPTY32) break;                               // this record is the slot's representative
                     }
-                    const uint32_t rep = o & 0xFFFFu;
-                    if (rlo[rep] == ml && rhi[rep] == mh) { atomicAdd(&own[hs], 1u << 16); append = false; break; }
+                    if (rlo[o] == ml && rhi[o] == mh) { rep = o; break; }
                     hs = (hs + 1) & (SK_C_DT - 1);
                 }
-                if (append) dl[atomicAdd(&sh[0], 1u)] = (uint16_t)entry;
-            }
-            __syncthreads();
-            // ---- expand every distinct record once
-            const uint32_t ndl = sh[0];
-            for (uint32_t e = tid; e < ndl; e += CT) {
-                const uint32_t ent = dl[e];
-                uint32_t r, mult;
-                if (ent & 0x8000u) { r = ent & 0x7FFFu; mult = 1; }
-                else { const uint32_t o = own[ent]; r = o & 0xFFFFu; mult = o >> 16; }
-                const uint64_t lo = rlo[r], hw = rhi[r];
-                const uint32_t nk = SK_REC_NK(hw);
-                const uint64_t hb = hw & SK_HI_BASES;
-                for (uint32_t j = 0; j < nk; ++j) {
-                    const uint64_t key = kdf_canon_narrow(kdf_funnel(lo, hb, 2 * (int)j), k, kmask);
-                    const uint64_t hsh = kdf_mix64(key);
-                    if (sliced && kdf_slice(hsh, plan.key_parts) != plan.key_part) continue;
-                    nwin += mult;
-                    uint32_t sl = (uint32_t)(hsh >> (64 - plan.bucket_bits));
-                    const uint32_t lim = B < KDF_SK_MAXPROBE ? B : KDF_SK_MAXPROBE;
-                    bool placed = false;
-                    for (uint32_t n = 0; n < lim; ++n) {
-                        uint64_t cur = tlo[sl];
-                        if (cur == KDF_EMPTY) {
-                            cur = atomicCAS((unsigned long long *)&tlo[sl], KDF_EMPTY, key);
-                            if (cur == KDF_EMPTY) { ++claimed; cur = key; }
-                        }
-                        if (cur == key) { atomicAdd(&tcnt[sl], mult); placed = true; break; }
-                        sl = (sl + 1) & bmask;
-                    }
-                    if (!placed) {                                             // the key's neighbourhood is full: overflow table
-                        if constexpr (MODE == SK_MODE_REPLAY) {
-                            const uint32_t p = atomicAdd(&s.ctrs[SKC_SPILL], 1u);
-                            if (p < s.sp_cap) { s.sp_key[p] = key; s.sp_cnt[p] = mult; }
-                            else s.ctrs[SKC_SPILL_LOST] = 1;                   // host sized the list for the worst case: never taken
-                        } else {
-                            const uint32_t q = atomicAdd(&sh[1], 1u);
-                            if (q < SK_C_SQ) { sqk[q] = key; sqc[q] = mult; }
-                            else failed = true;
-                        }
+                // (16-bit halves of one 32-bit word: the add cannot carry, a round has <= 1024 records)
+                atomicAdd((uint32_t *)mr + (rep >> 1), (rep & 1) ? 0x10000u : 1u);
+                if (rep == i) {
+                    const uint32_t nk = SK_REC_NK(mh);
+                    const uint32_t base = atomicAdd(&sh[0], nk);
+                    if (base + nk <= SK_C_IC) {
+#pragma unroll 4
+                        for (uint32_t j = 0; j < nk; ++j) items[base + j] = (uint16_t)((i << 5) | j);
+                    } else {                                                   // no room: the reserved part of the list holds no items
+                        pend_ent[pend_n++] = i;
+                        for (uint32_t q = base; q < SK_C_IC; ++q) { if (q >= base + nk) break; items[q] = 0xFFFFu; }
                     }
                 }
             }
             __syncthreads();
+            SK_STAMP(3)
+            // ---- expand: every distinct record's k-mers once, count += multiplicity.  Flat list: four items per
+            // thread at a time, their first-slot reads in flight together.
+            const uint32_t nit = (plan.dbg & 64) ? 0u : min(sh[0], (uint32_t)SK_C_IC);
+            {
+                // A wave of 64 lanes pays the LONGEST probe of its lanes for every key, so the common case -- the key or
+                // an empty slot within the first two slots -- is straight-line code over four items at once (eight slot
+                // reads in flight), and the keys that need more go to a wave-private queue (ballot + mbcnt: no atomics,
+                // no barrier) that is drained densely, one key per lane (kernel C's scheme, kdf_binned.h).
+                uint64_t *wqk = qk + (tid >> 6) * SK_C_WQ; uint32_t *wqm = qm + (tid >> 6) * SK_C_WQ; uint16_t *wqs = qs + (tid >> 6) * SK_C_WQ;
+                uint32_t wq_n = 0;
+                for (uint32_t i0 = tid & ~63u; i0 < nit; i0 += 4 * CT) {       // wave-uniform trip count
+                    uint64_t key[4], c0[4], c1[4]; uint32_t mult[4], sl0[4]; bool td[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t i = i0 + (tid & 63u) + u * CT;
+                        const uint32_t it = i < nit ? (uint32_t)items[i] : 0xFFFFu;
+                        td[u] = it != 0xFFFFu;
+                        key[u] = 0; mult[u] = 0; sl0[u] = 0;
+                        if (td[u]) td[u] = item_key(it, key[u], mult[u], sl0[u]);
+                        c0[u] = tlo[sl0[u]]; c1[u] = tlo[(sl0[u] + 1) & bmask];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(c0[u]), "+v"(c1[u]));    // all eight reads issued before the first key is resolved
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (!__any(td[u])) continue;
+                        uint32_t r = 2; bool hit = false;
+                        if (c1[u] == key[u] || c1[u] == KDF_EMPTY) { r = 1; hit = c1[u] == key[u]; }
+                        if (c0[u] == key[u] || c0[u] == KDF_EMPTY) { r = 0; hit = c0[u] == key[u]; }
+                        uint32_t sl = (sl0[u] + r) & bmask;
+                        bool more = td[u] && r == 2;
+                        hit = hit && td[u];
+                        if (td[u]) nwin += mult[u];
+                        if (td[u] && !more && !hit) {                            // read as empty: the CAS tells
+                            const uint64_t old = atomicCAS((unsigned long long *)&tlo[sl], KDF_EMPTY, key[u]);
+                            if (old == KDF_EMPTY) { ++claimed; hit = true; }
+                            else if (old == key[u]) hit = true;
+                            else { more = true; sl = (sl + 1) & bmask; }
+                        }
+                        if (hit) atomicAdd(&tcnt[sl], mult[u]);
+                        const unsigned long long mk = __ballot(more);
+                        if (mk) {
+                            const uint32_t at = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                            if (more) {
+                                if (at < SK_C_WQ) { wqk[at] = key[u]; wqm[at] = mult[u]; wqs[at] = (uint16_t)sl; }
+                                else if (!sk_slice_add(tlo, tcnt, bmask, lim, key[u], mult[u], sl, tlo[sl], claimed, (sl - sl0[u]) & bmask)) spill(key[u], mult[u]);
+                            }
+                            wq_n += (uint32_t)__popcll(mk);
+                        }
+                    }
+                    if (wq_n >= SK_C_WQ - 64 || i0 + 4 * CT >= nit) {            // drain (wave-uniform): dense probing, one queued key per lane
+                        const uint32_t nq = wq_n < SK_C_WQ ? wq_n : SK_C_WQ;
+                        for (uint32_t q = tid & 63u; q < nq; q += 64) {
+                            const uint64_t kq = wqk[q]; const uint32_t sq_ = wqs[q], mq = wqm[q];
+                            const uint32_t home = kdf_sk_slot(kq, plan.bucket_bits);
+                            if (!sk_slice_add(tlo, tcnt, bmask, lim, kq, mq, sq_, tlo[sq_], claimed, (sq_ - home) & bmask)) spill(kq, mq);
+                        }
+                        wq_n = 0;
+                    }
+                }
+            }
+            // records whose items did not fit the list (a bucket far above the mean): one k-mer after the other
+            for (uint32_t p_ = 0; p_ < pend_n; ++p_) {
+                const uint32_t nk = SK_REC_NK(rhi[pend_ent[p_]]);
+                for (uint32_t j = 0; j < nk; ++j) {
+                    uint64_t key; uint32_t mult, sl;
+                    if (!item_key((pend_ent[p_] << 5) | j, key, mult, sl)) continue;
+                    nwin += mult;
+                    if (!sk_slice_add(tlo, tcnt, bmask, lim, key, mult, sl, tlo[sl], claimed)) spill(key, mult);
+                }
+            }
+            __syncthreads();
+            SK_STAMP(4)
         }
     }
     if (failed) atomicOr(&sh[2], 1u);
@@ -585,16 +752,13 @@ __global__ __launch_bounds__(SK_C_THREADS) void sk_bucket_kernel(SkPlan plan, Sk
     if constexpr (MODE == SK_MODE_COUNT) {
         // reserve room for this bucket's spills; no room = the bucket fails as a whole
         if (tid == 0 && !sh[2] && sh[1]) {
+            // one fetch-add (a CAS loop collapses when hundreds of workgroups spill at once); a reservation that
+            // does not fit leaves a hole, which the zeroed count array marks (the host clears it before the pass)
             const uint32_t n = sh[1];
-            uint32_t old = s.ctrs[SKC_SPILL];
-            for (;;) {                                                         // CAS: a failed reservation leaves no hole in the list
-                if (old + n > s.sp_cap || old + n < old) { sh[2] = 1; break; }
-                const uint32_t seen = atomicCAS(&s.ctrs[SKC_SPILL], old, old + n);
-                if (seen == old) { sh[4] = old; break; }
-                old = seen;
-            }
+            const uint32_t base = atomicAdd(&s.ctrs[SKC_SPILL], n);
+            if (base >= s.sp_cap || n > s.sp_cap - base) sh[2] = 1; else sh[4] = base;
         }
-        __syncthreads();
+        if (sh[1]) __syncthreads();                                            // (sh[1] is uniform)
         if (sh[2]) {
             // transactional: leave the bucket as it was in HBM and flag it for the replay pass (a lazily
             // cleared table holds garbage there: write an empty slice instead)
@@ -608,7 +772,7 @@ __global__ __launch_bounds__(SK_C_THREADS) void sk_bucket_kernel(SkPlan plan, Sk
     }
     // write-back.  LDS counts were advanced with wrapping adds; a pass adds fewer than 2^32 to a slot, so a slot
     // wrapped iff its new value is below the value it had in HBM: saturate those (Jellyfish's 4-byte counter).
-    for (uint32_t i = tid; i < B / 2; i += CT) {
+    for (uint32_t i = tid; i < B / 2 && !(plan.dbg & 512); i += CT) {
         ((ulonglong2 *)(t.lo + slot0))[i] = ((const ulonglong2 *)tlo)[i];
         uint2 c = ((const uint2 *)tcnt)[i];
         if (load) {
@@ -618,6 +782,8 @@ __global__ __launch_bounds__(SK_C_THREADS) void sk_bucket_kernel(SkPlan plan, Sk
         }
         ((uint2 *)(t.cnt + slot0))[i] = c;
     }
+    SK_STAMP(5)
+    if (stampit) for (int i = 0; i < 6; ++i) atomicAdd(&s.ctrs[8 + i], st_acc[i] >> 6);
     if (tid == 0) {
         const uint32_t shard = (uint32_t)(bucket % KDF_SHARDS) * 16;
         if (sh[3]) atomicAdd(&ctl->distinct[shard], (unsigned long long)sh[3]);
@@ -630,7 +796,7 @@ __global__ __launch_bounds__(256) void sk_spill_insert_kernel(SkScratch s, KdfTa
     const uint32_t n = min(s.ctrs[SKC_SPILL], s.sp_cap);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t claimed = 0; bool full = false;
-    if (i < n && !kdf_sk_ovf_add<true>(t, s.sp_key[i], s.sp_cnt[i], claimed)) full = true;
+    if (i < n && s.sp_cnt[i] && !kdf_sk_ovf_add<true>(t, s.sp_key[i], s.sp_cnt[i], claimed)) full = true;     // count 0: a hole
     if (full) atomicOr(&ctl->error, 1u);
     uint32_t c = claimed;
 #pragma unroll
@@ -673,4 +839,80 @@ __global__ __launch_bounds__(256) void sk_ovf_rehash_kernel(const uint64_t *__re
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(ctr, c);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Balanced minimizer -> bucket assignment.  With m = 12 only a few "active" minimizers land in each bucket and
+// their sizes differ widely, so the fullest bucket of a plain hash holds about twice the mean.  Weights are sampled
+// from the first batch's records (every SK_WSAMPLE-th chunk: k-mer instances per minimizer) or taken from the live
+// table (one per stored key, when a table grows); per coarse bin the active minimizers are sorted by weight and
+// dealt to the bin's buckets in snake order (heaviest first).
+#define SK_WSAMPLE 8
+#define SK_A_CAP   12288                  // active minimizers of one coarse bin the sort holds (8 B each)
+
+__global__ __launch_bounds__(256) void sk_weight_records_kernel(SkScratch s, uint32_t *__restrict__ weights) {
+    // every SK_WSAMPLE-th chunk OF EACH BIN (chunk ids are handed out bin after bin within a round, so a stride over
+    // the ids would sample some bins only)
+    const uint32_t n_chunks = min(s.ctrs[SKC_POOL], s.max_chunks);
+    const uint32_t c = blockIdx.x;
+    if (s.ctrs[SKC_EXHAUSTED] || c >= n_chunks || s.chunk_pos[c] % SK_WSAMPLE) return;
+    const uint32_t fill = s.chunk_fill[c];
+    if (threadIdx.x < fill) {
+        const SkRec v = s.chunks[(size_t)c * SK_CHUNK + threadIdx.x];
+        atomicAdd(&weights[kdf_sk_spread(sk_rec_order(v.lo, v.hi))], SK_REC_NK(v.hi));
+    }
+}
+__global__ __launch_bounds__(256) void sk_weight_table_kernel(const uint64_t *__restrict__ klo, uint64_t n, int k, uint32_t *__restrict__ weights) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && klo[i] != KDF_EMPTY) atomicAdd(&weights[kdf_sk_spread(kdf_sk_min_of_key(klo[i], k))], 1u);
+}
+// one workgroup per coarse bin; assign[h] for every h of the bin
+__global__ __launch_bounds__(1024) void sk_assign_kernel(const uint32_t *__restrict__ weights, uint16_t *__restrict__ assign, uint32_t c1, uint32_t c2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long *ent = (unsigned long long *)smem;                      // [SK_A_CAP] weight << 32 | h offset
+    __shared__ uint32_t n_act;
+    const uint32_t H = 1u << (24 - c1), h0 = blockIdx.x << (24 - c1), nf = 1u << c2, tid = threadIdx.x;
+    __shared__ uint32_t whist[33], wmin;
+    if (tid == 0) n_act = 0;
+    if (tid < 33) whist[tid] = 0;
+    __syncthreads();
+    // The sort holds SK_A_CAP minimizers; a bin may have more with a non-zero weight (most of them light).  Take the
+    // heaviest weight classes (bit lengths) that fit; the light rest keeps the default bucket.
+    for (uint32_t i = tid; i < H; i += 1024) { const uint32_t w = weights[h0 + i]; if (w) atomicAdd(&whist[32 - __clz(w)], 1u); }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0, c = 32;
+        while (c >= 1 && acc + whist[c] <= SK_A_CAP) { acc += whist[c]; --c; }
+        wmin = c >= 32 ? 0xFFFFFFFFu : (c == 0 ? 1u : (1u << c));            // weights >= wmin are sorted
+    }
+    __syncthreads();
+    const uint32_t wthr = wmin;
+    // default for every h: the next bits of h (what the table-less layout uses); the sorted ones are overwritten below
+    for (uint32_t i = tid; i < H; i += 1024) {
+        const uint32_t w = weights[h0 + i];
+        assign[h0 + i] = (uint16_t)(c2 ? ((i >> (24 - c1 - c2)) & (nf - 1)) : 0u);
+        if (w >= wthr) { const uint32_t p = atomicAdd(&n_act, 1u); if (p < SK_A_CAP) ent[p] = ((unsigned long long)w << 32) | i; }
+    }
+    __syncthreads();
+    const uint32_t n = min(n_act, (uint32_t)SK_A_CAP);
+    uint32_t np2 = 1; while (np2 < n) np2 <<= 1;
+    for (uint32_t i = n + tid; i < np2; i += 1024) ent[i] = 0ull;              // (np2 <= 16384 entries = 128 KB)
+    __syncthreads();
+    // bitonic sort, descending (ties broken by h: deterministic whatever order the atomics appended in)
+    for (uint32_t kk = 2; kk <= np2; kk <<= 1)
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < np2; i += 1024) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const unsigned long long a = ent[i], b = ent[l];
+                    const bool desc = (i & kk) == 0;
+                    if (desc ? a < b : a > b) { ent[i] = b; ent[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const uint32_t round = i >> c2, pos = i & (nf - 1);
+        assign[h0 + (uint32_t)(ent[i] & 0xFFFFFFFFu)] = (uint16_t)((round & 1) ? nf - 1 - pos : pos);
+    }
 }

@@ -13,7 +13,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = colle
 for f in glob.glob("gpurun_out/pmc_c/p*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if not k.startswith("kb_"): continue
+        if not (k.startswith("kb_") or k.startswith("sk_")): continue
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
 for k in sorted(acc):
     print(k)

@@ -61,7 +61,7 @@ def test_superkmer_count_matches_oracle(oracle, k, hint):
         e.set_option("force_path", 3)
         half = len(reads) // 2
         e.count(ReadStream.from_strings(reads[:half]))         # empty table -> minimizer-bucketed layout
-        assert e.get_stat("layout") == 1 and e.last_count_path() == "superkmer"
+        assert e.get_stat("layout") >= 1 and e.last_count_path() == "superkmer"
         e.count(ReadStream.from_strings(reads[half:]))         # the second batch finds a non-empty SK table
         assert e.get_stat("sk_passes") >= 2
         check_equal(e, oracle, k, reads, lo, hi, cnt)
