@@ -354,17 +354,20 @@ def run_parent_filter(args, world, rank, local_rank):
     # filter = the child's non-reference k-mers with count >= 3 (what _subtract_reference_kmers hands on)
     child = synth_stream(reads, L, genome_len, seed=20260420, device=dev, genome=child_g)
     eng = KmerEngine(k, capacity_hint=1 << 28, device=local_rank)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()                  # the engine launches on its own stream: the generated streams must be complete
     eng.count_dev(child.packed.data_ptr(), child.invalid.data_ptr(), child.n_bases)
     n3 = eng.count_ge(3)
     cand = torch.empty(n3, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
     eng.export_ge_dev(3, cand.data_ptr(), None, None, n3)
     del child
     from kmer_denovo_filter_amd.synth import genome_stream
     gs = genome_stream(ref)
+    torch.cuda.synchronize()
     eng.clear()
     eng.count_dev(gs.packed.data_ptr(), gs.invalid.data_ptr(), gs.n_bases)
     in_ref = torch.empty(n3, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
     eng.query_dev(cand.data_ptr(), None, n3, in_ref.data_ptr())
     eng.synchronize()
     filt = cand[in_ref == 0].contiguous()
@@ -378,7 +381,6 @@ def run_parent_filter(args, world, rank, local_rank):
         print(f"[bench] synthetic trio built in {time.time() - t_gen:.1f}s: filter {n_filter} keys, "
               f"{per_rank} parent reads per rank", file=sys.stderr)
     feng = KmerEngine(k, capacity_hint=max(n_filter, 1 << 10), device=local_rank)
-    feng.set_stream(torch.cuda.current_stream().cuda_stream)
     feng.load_filter_dev(filt.data_ptr(), None, n_filter)
     eng.close()
     counts = torch.zeros(n_filter, dtype=torch.int32, device=dev)
@@ -394,6 +396,7 @@ def run_parent_filter(args, world, rank, local_rank):
         feng.count_filtered_dev(parent.packed.data_ptr(), parent.invalid.data_ptr(), parent.n_bases)
         if sharded is None:
             feng.query_dev(filt.data_ptr(), None, n_filter, counts.data_ptr())
+            feng.synchronize()
             c = counts
         else:
             c = sharded.merged_counts(filt, None)

@@ -58,36 +58,41 @@ def run(genome_len, coverage, k, seed, device, snv_rate=0.001, min_child_count=3
         eng.synchronize()
         return eng.stats()[2]
 
+    from kmer_denovo_filter_amd import devkeys
     ref = KmerEngine(k, capacity_hint=genome_len)
     w_ref = timed("ref_index", lambda: count(ref, streams["ref"]))
     child = KmerEngine(k, capacity_hint=max(1 << 20, genome_len * 6))
     w_child = timed("child_count", lambda: count(child, streams["child"]))
     out["stages"]["child_count"]["Gkmer_per_s"] = round(w_child / (out["stages"]["child_count"]["ms"] * 1e-3) / 1e9, 2)
-    cand = timed("dump_L", lambda: child.export_ge(min_child_count))
-    out["child_windows"], out["child_distinct"], out["candidates"] = w_child, child.stats()[1], len(cand[0])
+    out["stages"]["child_count"]["path"] = child.last_count_path()
+    # the chain stays in HBM (kmer_denovo_filter_amd/devkeys.py): dump -L into device buffers, query_dev, device masks,
+    # load_filter_dev; nothing is sorted or copied to the host until the surviving set is handed back
+    dlo, dhi = timed("dump_L", lambda: devkeys.dump_ge(child, min_child_count))
+    out["child_windows"], out["child_distinct"], out["candidates"] = w_child, child.stats()[1], int(dlo.numel())
     child.close()
-    refc = timed("ref_subtract", lambda: ref.query(cand[0], cand[1]))
-    keep = refc == 0
-    lo, hi = cand[0][keep], cand[1][keep]
-    out["non_ref"] = len(lo)
+    keep = timed("ref_subtract", lambda: devkeys.query(ref, dlo, dhi) == 0)
+    dlo, dhi = dlo[keep].contiguous(), (dhi[keep].contiguous() if dhi is not None else None)
+    out["non_ref"] = int(dlo.numel())
     ref.close()
     for label in ("mother", "father"):
-        eng = KmerEngine(k, capacity_hint=max(len(lo), 1))
+        eng = KmerEngine(k, capacity_hint=max(int(dlo.numel()), 1))
         ds = streams[label]
 
         def stage():
-            eng.load_filter(lo, hi)
+            eng.load_filter_dev(dlo.data_ptr(), dhi.data_ptr() if dhi is not None else None, int(dlo.numel()))
             eng.count_filtered_dev(ds.packed.data_ptr(), ds.invalid.data_ptr(), ds.n_bases)
-            return eng.query(lo, hi)
+            return devkeys.query(eng, dlo, dhi)
         c = timed(f"{label}_count_if", stage)
-        w = int(n_reads * (L - k + 1) * 0.964)
-        out["stages"][f"{label}_count_if"]["Gkmer_per_s"] = round(w / (out["stages"][f"{label}_count_if"]["ms"] * 1e-3) / 1e9, 2)
-        out["stages"][f"{label}_count_if"]["filter_keys"] = len(lo)
+        w = eng.stats()[2]
+        st = out["stages"][f"{label}_count_if"]
+        st["Gkmer_per_s"] = round(w / (st["ms"] * 1e-3) / 1e9, 2)
+        st["filter_keys"] = int(dlo.numel()); st["windows"] = w; st["path"] = eng.last_count_path()
         eng.close()
         keep = c <= parent_max_count
-        lo, hi = lo[keep], hi[keep]
-        out[f"after_{label}"] = len(lo)
-    out["proband_unique"] = len(lo)
+        dlo, dhi = dlo[keep].contiguous(), (dhi[keep].contiguous() if dhi is not None else None)
+        out[f"after_{label}"] = int(dlo.numel())
+    out["proband_unique"] = int(dlo.numel())
+    lo, hi = devkeys.to_host(dlo, dhi)
     return out, (lo, hi), streams
 
 
@@ -97,5 +102,6 @@ if __name__ == "__main__":
     ap.add_argument("--coverage", type=int, default=30)
     ap.add_argument("--k", type=int, default=31)
     args = ap.parse_args()
+    run(args.genome, args.coverage, args.k, 20260418, "cuda:0")       # first run: one-time allocations, code-object loads
     res, _, _ = run(args.genome, args.coverage, args.k, 20260418, "cuda:0")
     print(json.dumps(res))

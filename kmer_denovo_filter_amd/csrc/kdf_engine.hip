@@ -222,6 +222,90 @@ __global__ __launch_bounds__(256) void kdf_export_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// count --if through a membership sieve.  In the parent-filter / VCF stages almost every window MISSES the filter
+// (discovery/pipeline.py:377-443: a whole parent's reads against the child's candidate k-mers), so partitioning
+// every window (binned path) or probing the hash table for every window (direct path) is wasted work.  The filter
+// keys are folded into a blocked Bloom filter (two bits inside ONE 64-bit word per key; 16-32 bits per key, so it
+// lives in L2 / the Infinity Cache); a window costs its canonical k-mer, one hash and ONE word load, and only the
+// survivors (hits + a 0.4-1.4 % false-positive share) probe the table -- densely, 64 at a time from a wave-private
+// LDS queue (ballot + mbcnt, no atomics, no barrier), so the rare slow path runs with every lane busy.
+struct KdfSieve { const uint64_t *words; uint64_t wmask; };
+
+__device__ __forceinline__ void kdf_sieve_bits(uint64_t hsh, uint64_t wmask, uint64_t &word, uint64_t &bits) {
+    word = (hsh >> 12) & wmask;
+    bits = (1ull << (hsh & 63)) | (1ull << ((hsh >> 6) & 63));
+}
+
+template <int KW>
+__global__ __launch_bounds__(256) void kdf_sieve_build_kernel(const uint64_t *__restrict__ klo, const uint64_t *__restrict__ khi, uint64_t n,
+                                                             uint64_t *__restrict__ words, uint64_t wmask) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t w, b;
+    kdf_sieve_bits(kdf_hash(klo[i], KW == 2 ? khi[i] : 0), wmask, w, b);
+    atomicOr((unsigned long long *)&words[w], (unsigned long long)b);
+}
+
+#define KDF_SV_WQ 128                     // queue entries per wave (drained 64 at a time)
+template <int KW>
+__global__ __launch_bounds__(KB_THREADS) void kdf_sieve_count_kernel(
+    const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid, uint64_t n_tiles, int k,
+    KdfTable t, KdfCtl *ctl, KdfSieve sv, uint32_t slabs_per_wg)
+{
+    constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT;
+    constexpr uint32_t TILES_PER_SLAB = KB_THREADS / TPT;
+    __shared__ uint64_t qlo[(KB_THREADS / 64) * KDF_SV_WQ];
+    __shared__ uint64_t qhi[KW == 2 ? (KB_THREADS / 64) * KDF_SV_WQ : 1];
+    uint64_t *wqlo = qlo + (threadIdx.x >> 6) * KDF_SV_WQ, *wqhi = qhi + (KW == 2 ? (threadIdx.x >> 6) * KDF_SV_WQ : 0);
+    const int lane = threadIdx.x & 63;
+    uint32_t wq_n = 0, nwin = 0, claimed = 0;
+    bool full = false;
+    // probe the table for 64 queued keys (or the rest): every lane has a key
+    auto drain = [&](uint32_t from, uint32_t cnt) {
+        const bool todo = (uint32_t)lane < cnt;
+        const uint64_t klo = todo ? wqlo[from + lane] : 0, khi = (KW == 2 && todo) ? wqhi[from + lane] : 0;
+        const uint64_t slot = kdf_home(t, kdf_hash(klo, khi));
+        if constexpr (KW == 1) { if (todo && !kdf_add_narrow<false>(t, klo, 1u, slot, t.lo[slot], claimed)) full = true; }
+        else { if (!kdf_add_wide<false>(t, todo, klo, khi, 1u, slot, claimed)) full = true; }
+    };
+    const uint64_t slab0 = (uint64_t)blockIdx.x * slabs_per_wg;
+    for (uint32_t sl = 0; sl < slabs_per_wg; ++sl) {
+        if ((slab0 + sl) * TILES_PER_SLAB >= n_tiles) break;
+        const uint64_t tile = (slab0 + sl) * TILES_PER_SLAB + threadIdx.x / TPT;
+        KbWindows<KW> win;
+        win.load(packed, invalid, tile, n_tiles, threadIdx.x % TPT, k);
+        uint64_t klo[WPT], khi[KW == 2 ? WPT : 1], w[WPT], bits[WPT];
+#pragma unroll
+        for (int u = 0; u < WPT; ++u) {                         // WPT sieve words in flight per lane
+            uint64_t lo, hi; win.key(u, lo, hi);
+            klo[u] = lo; if constexpr (KW == 2) khi[u] = hi;
+            uint64_t wi;
+            kdf_sieve_bits(kdf_hash(lo, hi), sv.wmask, wi, bits[u]);
+            w[u] = sv.words[wi];
+        }
+        nwin += __popc(win.valid);
+#pragma unroll
+        for (int u = 0; u < WPT; ++u) {
+            const bool ok = ((win.valid >> u) & 1) && (w[u] & bits[u]) == bits[u];
+            const unsigned long long mk = __ballot(ok);
+            if (mk) {
+                const uint32_t at = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                if (ok) { wqlo[at] = klo[u]; if constexpr (KW == 2) wqhi[at] = khi[u]; }
+                wq_n += (uint32_t)__popcll(mk);
+                if (wq_n >= 64) { wq_n -= 64; drain(wq_n, 64); }            // (wave-uniform)
+            }
+        }
+    }
+    if (wq_n) drain(0, wq_n);
+    if (full) atomicOr(&ctl->error, 1u);
+    uint32_t n = nwin;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
+    if (lane == 0 && n) atomicAdd(&ctl->windows[((blockIdx.x * 16 + (threadIdx.x >> 6)) % KDF_SHARDS) * 16], (unsigned long long)n);
+}
+
 __global__ void kdf_ctl_reduce_kernel(KdfCtl *ctl, unsigned long long *out3) {
     // out3 = {distinct, windows, error}; single wave
     unsigned long long d = ctl->distinct[threadIdx.x * 16], w = ctl->windows[threadIdx.x * 16], y = ctl->tally[threadIdx.x * 16];
@@ -278,7 +362,10 @@ struct kdf_engine {
     uint32_t sk_assign_c1 = 0, sk_assign_c2 = 0;     // 0 / 0: no table yet
     int opt_sk_balance = 1;
     uint64_t stat_sk_passes = 0, stat_sk_spills = 0, stat_sk_failed = 0, stat_sk_fallbacks = 0;
-    int last_path = 0;                               // count path of the last count call: 0 direct, 1 binned, 2 super-k-mer
+    int last_path = 0;                               // count path of the last count call: 0 direct, 1 binned, 2 super-k-mer, 3 sieve
+    uint64_t *sieve = nullptr;                       // blocked Bloom filter over the filter keys (count --if)
+    uint64_t sieve_words = 0, sieve_alloc = 0;
+    bool sieve_valid = false;
     uint32_t opt_debug_flags = 0;                    // experiments only (KbPlan::dbg)
     uint64_t stat_binned_passes = 0, stat_replayed_buckets = 0;
     uint64_t stat_dbg[6] = {0, 0, 0, 0, 0, 0};        // diagnostic stamps of the last binned pass
@@ -1117,7 +1204,27 @@ static int count_filtered_dev(kdf_engine *h, const uint64_t *d_packed, const uin
     const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
     if (n_tiles == 0) return KDF_OK;
     { int rc0 = materialize(h); if (rc0) return rc0; }
-    if (use_binned(h, n_bases, true)) return kb_passes(h, d_packed, d_invalid, n_bases, true);
+    if (h->sieve_valid && !h->t.sk && (h->opt_force_path == 0 || h->opt_force_path == 4)) {
+        // persistent workgroups over slabs of 1024 x WPT positions
+        const int WPT = h->kw == 1 ? KbCfg<1>::WPT : KbCfg<2>::WPT;
+        const uint64_t tiles_per_slab = KB_THREADS / (64 / WPT);
+        const uint64_t n_slabs = (n_tiles + tiles_per_slab - 1) / tiles_per_slab;
+        const uint32_t n_wg = (uint32_t)std::min<uint64_t>(n_slabs, (uint64_t)h->n_cu * 8);
+        const uint32_t spw = (uint32_t)((n_slabs + n_wg - 1) / n_wg);
+        const unsigned grid = (unsigned)((n_slabs + spw - 1) / spw);
+        KdfSieve sv{h->sieve, h->sieve_words - 1};
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (h->prof) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, h->stream); }
+        if (h->kw == 1) hipLaunchKernelGGL(kdf_sieve_count_kernel<1>, dim3(grid), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->k, h->t, h->ctl, sv, spw);
+        else hipLaunchKernelGGL(kdf_sieve_count_kernel<2>, dim3(grid), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->k, h->t, h->ctl, sv, spw);
+        if (h->prof) { (void)hipEventRecord(e1, h->stream); h->prof_ev.emplace_back(e0, e1); h->prof_tiles.push_back(n_tiles); }
+        HIPCHK(h, hipGetLastError());
+        h->last_path = 3;
+        return KDF_OK;
+    }
+    if (h->opt_force_path == 4) return fail(h, KDF_ERR_STATE, "force_path 4 (sieve): no sieve for this filter (more than 2^27 keys, or keys were added after kdf_load_filter)");
+    if (use_binned(h, n_bases, true)) { h->last_path = 1; return kb_passes(h, d_packed, d_invalid, n_bases, true); }
+    h->last_path = 0;
     launch_stream<MODE_FILTERED>(h, d_packed, d_invalid, 0, n_tiles, nullptr);
     HIPCHK(h, hipGetLastError());
     return KDF_OK;
@@ -1193,6 +1300,7 @@ void kdf_destroy(kdf_engine *h) {
     for (int i = 0; i < 4; ++i) if (h->stage[i]) (void)hipFree(h->stage[i]);
     for (int i = 0; i < 6; ++i) if (h->kb_buf[i]) (void)hipFree(h->kb_buf[i]);
     for (int i = 0; i < 16; ++i) if (h->sk_buf[i]) (void)hipFree(h->sk_buf[i]);
+    if (h->sieve) (void)hipFree(h->sieve);
     if (h->sk_assign) (void)hipFree(h->sk_assign);
     if (h->sk_weights) (void)hipFree(h->sk_weights);
     if (h->sk_ctrs) (void)hipFree(h->sk_ctrs);
@@ -1226,7 +1334,7 @@ int kdf_clear(kdf_engine *h) {
     int rc = ctl_reset(h, false);
     if (rc) return rc;
     h->distinct = 0; h->windows = 0; h->filter_mode = false;
-    h->lazy_empty = true;
+    h->lazy_empty = true; h->sieve_valid = false;
     sk_leave(h);                  // layouts are chosen per table generation: the next count decides again
     return KDF_OK;
 }
@@ -1275,6 +1383,7 @@ int kdf_count_reads(kdf_engine *h, const uint64_t *packed, const uint64_t *inval
 // the table becomes exactly the n keys at d_lo / d_hi (device arrays) with count 0
 static int load_filter_core(kdf_engine *h, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t n) {
     int rc;
+    h->sieve_valid = false;
     // size the table for n keys at load <= 0.5, then start from empty
     const uint32_t want = cap_log2_for(n);
     if (want != h->t.log2cap) {
@@ -1287,18 +1396,39 @@ static int load_filter_core(kdf_engine *h, const uint64_t *d_lo, const uint64_t 
     } else if ((rc = kdf_clear(h))) return rc;
     if ((rc = materialize(h))) return rc;
     h->filter_mode = true;
-    if (n == 0) return KDF_OK;
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    if (h->kw == 1)
-        hipLaunchKernelGGL(kdf_insert_keys_kernel<1>, dim3(blocks), dim3(256), 0, h->stream,
-                           d_lo, (const uint64_t *)nullptr, (const uint32_t *)nullptr, n, h->t, h->ctl, 0);
-    else
-        hipLaunchKernelGGL(kdf_insert_keys_kernel<2>, dim3(blocks), dim3(256), 0, h->stream,
-                           d_lo, d_hi, (const uint32_t *)nullptr, n, h->t, h->ctl, 0);
-    HIPCHK(h, hipGetLastError());
-    bool full = false;
-    if ((rc = ctl_sync(h, &full))) return rc;
-    if (full) return fail(h, KDF_ERR_TABLE_FULL, "kdf_load_filter: bucket overflow");
+    if (n) {
+        if (h->kw == 1)
+            hipLaunchKernelGGL(kdf_insert_keys_kernel<1>, dim3(blocks), dim3(256), 0, h->stream,
+                               d_lo, (const uint64_t *)nullptr, (const uint32_t *)nullptr, n, h->t, h->ctl, 0);
+        else
+            hipLaunchKernelGGL(kdf_insert_keys_kernel<2>, dim3(blocks), dim3(256), 0, h->stream,
+                               d_lo, d_hi, (const uint32_t *)nullptr, n, h->t, h->ctl, 0);
+        HIPCHK(h, hipGetLastError());
+        bool full = false;
+        if ((rc = ctl_sync(h, &full))) return rc;
+        if (full) return fail(h, KDF_ERR_TABLE_FULL, "kdf_load_filter: bucket overflow");
+    }
+    // the membership sieve over the same keys: 32 bits per key up to 2^20 keys, 16 beyond (it should live in L2 /
+    // the Infinity Cache); none past 2^27 keys
+    h->sieve_valid = false;
+    if (n <= (1ull << 27)) {
+        const uint64_t bits = n * (n <= (1ull << 20) ? 32 : 16);
+        const uint64_t words = std::max<uint64_t>(1024, 1ull << log2ceil((bits + 63) / 64));
+        if (h->sieve_alloc < words) {
+            if (h->sieve) (void)hipFree(h->sieve);
+            h->sieve = nullptr; h->sieve_alloc = 0;
+            HIPCHK(h, hipMalloc((void **)&h->sieve, words * 8));
+            h->sieve_alloc = words;
+        }
+        h->sieve_words = words;
+        HIPCHK(h, hipMemsetAsync(h->sieve, 0, words * 8, h->stream));
+        if (n == 0) {}                                           // an empty filter: the all-zero sieve lets nothing through
+        else if (h->kw == 1) hipLaunchKernelGGL(kdf_sieve_build_kernel<1>, dim3(blocks), dim3(256), 0, h->stream, d_lo, (const uint64_t *)nullptr, n, h->sieve, words - 1);
+        else hipLaunchKernelGGL(kdf_sieve_build_kernel<2>, dim3(blocks), dim3(256), 0, h->stream, d_lo, d_hi, n, h->sieve, words - 1);
+        HIPCHK(h, hipGetLastError());
+        h->sieve_valid = true;
+    }
     return KDF_OK;
 }
 
@@ -1341,6 +1471,7 @@ int kdf_reset_counts(kdf_engine *h) {
 // pairs fit at load <= 0.5 even if all of them are new
 static int add_pairs_dev(kdf_engine *h, const uint64_t *d_lo, const uint64_t *d_hi, const uint32_t *d_cnt, uint64_t n) {
     if (n == 0) return KDF_OK;
+    h->sieve_valid = false;                          // keys may join the table that the sieve has not seen
     int rc = materialize(h);
     if (rc) return rc;
     if ((rc = ctl_sync(h, nullptr))) return rc;

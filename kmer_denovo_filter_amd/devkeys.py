@@ -1,0 +1,80 @@
+"""Key sets that stay in HBM between the discovery stages.
+
+The reference hands k-mer sets from stage to stage as FASTA files
+(``child_candidates.fa`` -> ``child_non_ref_kmers.fa`` -> ``after_mother.fa`` ->
+``proband_unique.fa``; discovery/pipeline.py:207-226,286-304,515-532).  The
+mirror keeps that contract -- every file is still written, in the reference's
+``>{i}\\n{KMER}\\n`` form -- but a stage that finds the set of its input path in
+this registry takes the keys from device memory (``kdf_load_filter_dev`` /
+``kdf_query_dev``) instead of parsing the text back and copying it up again.
+torch is the holder of the device arrays here, nothing more.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+_registry: Dict[str, Tuple[object, Optional[object], int]] = {}
+
+
+def _key(path: str) -> str:
+    return os.path.abspath(path)
+
+
+def register(path: str, lo, hi, k: int):
+    """``lo`` / ``hi``: int64 CUDA tensors (bit patterns of the uint64 key words); hi None for k <= 32."""
+    _registry[_key(path)] = (lo, hi, int(k))
+
+
+def lookup(path: str, k: int):
+    """(lo, hi) device tensors registered for ``path`` at this k, or None."""
+    ent = _registry.get(_key(path))
+    if ent is None or ent[2] != int(k) or not os.path.exists(path):
+        return None
+    return ent[0], ent[1]
+
+
+def forget(path: str):
+    _registry.pop(_key(path), None)
+
+
+def to_host(lo, hi) -> Tuple[np.ndarray, np.ndarray]:
+    """Device key tensors -> the (lo, hi) uint64 arrays the FASTA writer takes."""
+    hlo = lo.cpu().numpy().view(np.uint64)
+    hhi = hi.cpu().numpy().view(np.uint64) if hi is not None else np.zeros(len(hlo), np.uint64)
+    return hlo, hhi
+
+
+def from_host(lo: np.ndarray, hi: Optional[np.ndarray], wide: bool, device: int = 0):
+    import torch
+    dev = torch.device("cuda", device)
+    tlo = torch.from_numpy(np.ascontiguousarray(lo, dtype=np.uint64).view(np.int64)).to(dev)
+    thi = torch.from_numpy(np.ascontiguousarray(hi, dtype=np.uint64).view(np.int64)).to(dev) if wide else None
+    return tlo, thi
+
+
+def dump_ge(eng, min_count: int, device: int = 0):
+    """``jellyfish dump -c -L min_count`` into device tensors (unsorted: the reference does not rely on the order)."""
+    import torch
+    dev = torch.device("cuda", device)
+    n = eng.count_ge(min_count)
+    lo = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    hi = torch.empty(max(n, 1), dtype=torch.int64, device=dev) if eng.wide else None
+    torch.cuda.current_stream(dev).synchronize()
+    got = eng.export_ge_dev(min_count, lo.data_ptr(), hi.data_ptr() if hi is not None else None, None, n) if n else 0
+    assert got == n
+    return lo[:n], (hi[:n] if hi is not None else None)
+
+
+def query(eng, lo, hi, device: int = 0):
+    """``jellyfish query``: uint32 counts (as int64 values) of the keys, input order, on the device."""
+    import torch
+    dev = torch.device("cuda", device)
+    out = torch.zeros(lo.numel(), dtype=torch.int32, device=dev)
+    if lo.numel():
+        torch.cuda.current_stream(dev).synchronize()
+        eng.query_dev(lo.data_ptr(), hi.data_ptr() if hi is not None else None, lo.numel(), out.data_ptr())
+        eng.synchronize()
+    return out.to(torch.int64) & 0xFFFFFFFF

@@ -20,7 +20,7 @@ import time
 
 import numpy as np
 
-from .. import jf_io
+from .. import devkeys, jf_io
 from .._native import KdfError
 from ..core.jellyfish_wrappers import (
     _engine_capacity_hint,
@@ -68,6 +68,7 @@ def _extract_child_kmers_discovery(child_bam, ref_fasta, kmer_size, min_child_co
     try:
         with KmerEngine(kmer_size, capacity_hint=max(1, _engine_capacity_hint(jf_hash_size, child_bam) // parts)) as eng:
             los, his = [], []
+            dev_sets = []
             if parts > 1:
                 eng.set_option("key_parts", parts)
             for part in range(parts):
@@ -79,12 +80,20 @@ def _extract_child_kmers_discovery(child_bam, ref_fasta, kmer_size, min_child_co
                             _format_elapsed(time.monotonic() - extract_start), part + 1, parts, windows, distinct, cap)
                 logger.info("Dumping child k-mers with count >= %d…", min_child_count)
                 dump_start = time.monotonic()
-                lo, hi, _ = eng.export_ge(min_child_count)
+                # the dump stays in HBM for the next stage (unsorted: Jellyfish's dump order is not reproducible
+                # either and nothing downstream relies on it); the FASTA below is the file contract
+                dlo, dhi = devkeys.dump_ge(eng, min_child_count, eng.device)
+                dev_sets.append((dlo, dhi))
+                lo, hi = devkeys.to_host(dlo, dhi)
                 los.append(lo); his.append(hi)
             lo, hi = (np.concatenate(los), np.concatenate(his)) if parts > 1 else (los[0], his[0])
+            if parts > 1:
+                import torch
+                dev_sets = [(torch.cat([d[0] for d in dev_sets]), torch.cat([d[1] for d in dev_sets]) if eng.wide else None)]
     except KdfError as e:
         raise RuntimeError(f"jellyfish count (child) failed: {e}") from e
     n_candidates = write_kmer_fasta(child_candidates_fa, lo, hi, kmer_size)
+    devkeys.register(child_candidates_fa, dev_sets[0][0], dev_sets[0][1], kmer_size)
     logger.info("Child k-mer dump complete (%s, %d candidates, FASTA: %s)",
                 _format_elapsed(time.monotonic() - dump_start), n_candidates,
                 _format_file_size(child_candidates_fa))
@@ -104,16 +113,25 @@ def _subtract_reference_kmers(ref_jf, child_candidates_fa, tmpdir):
     child_non_ref_fa = os.path.join(tmpdir, "child_non_ref_kmers.fa")
     try:
         k, rlo, rhi, rcnt = jf_io.read_index(ref_jf)
-        lo, hi = read_kmer_fasta_keys(child_candidates_fa, k)
-        if len(lo):
+        dev = devkeys.lookup(child_candidates_fa, k)             # the candidates are still in HBM when Module 1 ran here
+        if dev is None:
+            lo, hi = read_kmer_fasta_keys(child_candidates_fa, k)
+            dev = devkeys.from_host(lo, hi, k > 32) if len(lo) else None
+        if dev is not None and dev[0].numel():
             with KmerEngine(k, capacity_hint=max(len(rlo), 1)) as eng:
                 eng.add_pairs(rlo, rhi, rcnt)
-                c = eng.query(lo, hi)
-            keep = c == 0
-            lo, hi = lo[keep], hi[keep]
+                keep = devkeys.query(eng, dev[0], dev[1], eng.device) == 0
+            dlo, dhi = dev[0][keep].contiguous(), (dev[1][keep].contiguous() if dev[1] is not None else None)
+            lo, hi = devkeys.to_host(dlo, dhi)
+        else:
+            dlo = dhi = None
+            lo = hi = np.zeros(0, np.uint64)
     except (KdfError, ValueError, OSError) as e:
         raise RuntimeError(f"jellyfish query (ref subtraction) failed: {e}") from e
     n_non_ref = write_kmer_fasta(child_non_ref_fa, lo, hi, k)
+    if dlo is not None:
+        devkeys.register(child_non_ref_fa, dlo, dhi, k)
+    devkeys.forget(child_candidates_fa)
     remove_with_sidecar(child_candidates_fa)
     logger.info("Non-reference child k-mers after subtraction: %d", n_non_ref)
     return child_non_ref_fa, n_non_ref
@@ -155,45 +173,73 @@ def _query_index(jf_path, lo, hi, k, what):
         raise RuntimeError(f"jellyfish query ({what}) failed: {e}") from e
 
 
+def _count_parent_on_device(parent_bam, ref_fasta, dlo, dhi, kmer_size, threads, label):
+    """The counting half of _count_parent_jellyfish with the filter taken from HBM; returns the engine (the
+    caller queries it and closes it: no ``parent.jf`` is written only to be read back)."""
+    logger.info("%s: scanning BAM (%s): %s", label, _format_file_size(parent_bam), parent_bam)
+    scan_start = time.monotonic()
+    logger.info("  BAM stream -> MI355X count --if (k=%d, threads=%d, filter_kmers=%d)", kmer_size, threads, dlo.numel())
+    eng = KmerEngine(kmer_size, capacity_hint=max(int(dlo.numel()), 1))
+    try:
+        eng.load_filter_dev(dlo.data_ptr(), dhi.data_ptr() if dhi is not None else None, int(dlo.numel()))
+        _stream_bam(eng, parent_bam, ref_fasta, threads, filtered=True)
+    except Exception:
+        eng.close()
+        raise
+    logger.info("  %s jellyfish counting complete (%s)", label, _format_elapsed(time.monotonic() - scan_start))
+    return eng
+
+
 def _filter_parents_discovery(mother_bam, father_bam, ref_fasta, child_non_ref_fa, kmer_size, threads, tmpdir,
                               parent_max_count=0):
     """Module 2: mother then father (on the survivors), keep
-    ``count <= parent_max_count``.  Returns (n_proband_unique, path | None)."""
-    lo, hi = read_kmer_fasta_keys(child_non_ref_fa, kmer_size)
-    n_input = len(lo)
+    ``count <= parent_max_count``.  Returns (n_proband_unique, path | None).
+
+    The key set stays in HBM from stage to stage: it is the parent's ``--if`` filter (kdf_load_filter_dev), the
+    engine that counted the parent answers the ``jellyfish query`` directly (kdf_query_dev), and the survivors
+    are a device-side mask.  ``after_mother.fa`` and ``proband_unique.fa`` are written as the reference writes them."""
+    try:
+        dev = devkeys.lookup(child_non_ref_fa, kmer_size)
+        if dev is None:
+            lo, hi = read_kmer_fasta_keys(child_non_ref_fa, kmer_size)
+            if len(lo) == 0:
+                return 0, None
+            dev = devkeys.from_host(lo, hi, kmer_size > 32)
+    except (KdfError, ValueError, OSError) as e:
+        raise RuntimeError(f"jellyfish count (Mother) failed: {e}") from e
+    dlo, dhi = dev
+    n_input = int(dlo.numel())
     if n_input == 0:
         return 0, None
     logger.info("Filtering %d non-reference k-mers against parents…", n_input)
 
-    mother_jf = _count_parent_jellyfish(mother_bam, ref_fasta, child_non_ref_fa, kmer_size,
-                                        os.path.join(tmpdir, "mother"), threads, label="Mother",
-                                        n_filter_kmers=n_input)
+    def one_parent(bam, label, dlo, dhi):
+        os.makedirs(os.path.join(tmpdir, label.lower()), exist_ok=True)
+        try:
+            eng = _count_parent_on_device(bam, ref_fasta, dlo, dhi, kmer_size, threads, label)
+            try:
+                keep = devkeys.query(eng, dlo, dhi, eng.device) <= parent_max_count
+            finally:
+                eng.close()
+        except (KdfError, ValueError, OSError) as e:
+            raise RuntimeError(f"jellyfish count ({label}) failed: {e}") from e
+        return dlo[keep].contiguous(), (dhi[keep].contiguous() if dhi is not None else None)
+
+    dlo, dhi = one_parent(mother_bam, "Mother", dlo, dhi)
     after_mother_fa = os.path.join(tmpdir, "after_mother.fa")
-    c = _query_index(mother_jf, lo, hi, kmer_size, "mother filter")
-    keep = c <= parent_max_count
-    n_surviving = write_kmer_fasta(after_mother_fa, lo[keep], hi[keep], kmer_size)
-    n_removed_mother = n_input - n_surviving
-    if os.path.exists(mother_jf):
-        os.remove(mother_jf)
+    n_surviving = write_kmer_fasta(after_mother_fa, *devkeys.to_host(dlo, dhi), kmer_size)
     logger.info("Mother: %d / %d non-ref k-mers found (count > %d), %d surviving",
-                n_removed_mother, n_input, parent_max_count, n_surviving)
+                n_input - n_surviving, n_input, parent_max_count, n_surviving)
     if n_surviving == 0:
         return 0, None
 
-    lo, hi = lo[keep], hi[keep]
-    father_jf = _count_parent_jellyfish(father_bam, ref_fasta, after_mother_fa, kmer_size,
-                                        os.path.join(tmpdir, "father"), threads, label="Father",
-                                        n_filter_kmers=n_surviving)
+    dlo, dhi = one_parent(father_bam, "Father", dlo, dhi)
     proband_unique_fa = os.path.join(tmpdir, "proband_unique.fa")
-    c = _query_index(father_jf, lo, hi, kmer_size, "father filter")
-    keep = c <= parent_max_count
-    n_proband = write_kmer_fasta(proband_unique_fa, lo[keep], hi[keep], kmer_size)
-    n_removed_father = n_surviving - n_proband
-    if os.path.exists(father_jf):
-        os.remove(father_jf)
+    n_proband = write_kmer_fasta(proband_unique_fa, *devkeys.to_host(dlo, dhi), kmer_size)
+    devkeys.register(proband_unique_fa, dlo, dhi, kmer_size)
     remove_with_sidecar(after_mother_fa)
     logger.info("Father: %d / %d surviving k-mers found (count > %d), %d proband-unique",
-                n_removed_father, n_surviving, parent_max_count, n_proband)
+                n_surviving - n_proband, n_surviving, parent_max_count, n_proband)
     logger.info("Proband-unique k-mers (absent from both parents): %d / %d", n_proband, n_input)
     logger.info("Proband-unique FASTA: %s (%s)", proband_unique_fa, _format_file_size(proband_unique_fa))
     return n_proband, proband_unique_fa

@@ -292,3 +292,43 @@ def test_table_too_large_is_a_clear_error():
     assert "key_parts" in str(ei.value) and "does not fit" in str(ei.value)
     with KmerEngine(31, capacity_hint=1 << 10) as e:      # the process is still usable afterwards
         assert e.stats()[1] == 0
+
+
+@pytest.mark.parametrize("k", [21, 31, 47])
+def test_count_filtered_through_the_sieve(oracle, k):
+    """count --if with the membership sieve (auto path; force_path 4 insists on it): every filter size from empty
+    to "every k-mer of the stream" (all windows survive the sieve and drain through the wave queues), a filter
+    loaded from device memory, counts kept across batches and zeroed by reset_counts."""
+    import torch
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    rng = np.random.default_rng(500 + k)
+    genome = rng.integers(0, 4, 50000).astype(np.uint8)
+    child = rand_reads(rng, 1500, 50, 260, genome=genome)
+    parent = rand_reads(rng, 3000, 0, 260, genome=genome) + ["A" * 300] * 20
+    _, (lo, hi, _) = oracle_sorted(oracle, k, child + ["A" * 100])
+    st1, st2 = ReadStream.from_strings(parent[:1000]), ReadStream.from_strings(parent[1000:])
+    for frac in (0.0, 0.01, 0.4, 1.0):
+        sel = rng.random(len(lo)) < frac if frac < 1.0 else np.ones(len(lo), bool)
+        flo, fhi = lo[sel], hi[sel]
+        ot = oracle.OracleTable(k, 1 << 12).load_filter(flo, fhi).count_reads_filtered(parent)
+        with KmerEngine(k) as e:
+            if frac == 0.4:                                   # device-resident filter keys
+                dl = torch.from_numpy(flo.view(np.int64).copy()).cuda()
+                dh = torch.from_numpy(fhi.view(np.int64).copy()).cuda() if k > 32 else None
+                e.load_filter_dev(dl.data_ptr(), dh.data_ptr() if dh is not None else None, len(flo))
+            else:
+                e.load_filter(flo, fhi)
+            e.set_option("force_path", 4)
+            e.count_filtered(st1); e.count_filtered(st2)
+            assert e.last_count_path() == "sieve"
+            assert e.stats()[2] == oracle.count_windows(parent, k)
+            np.testing.assert_array_equal(e.query(lo, hi), ot.query(lo, hi))
+            glo, _, gcnt = e.export_ge(0)
+            olo, _, ocnt = ot.export_ge(0)
+            np.testing.assert_array_equal(glo, olo); np.testing.assert_array_equal(gcnt, ocnt)
+            e.reset_counts()
+            assert int(e.query(lo, hi).sum()) == 0 and e.stats()[1] == len(flo)
+            e.set_option("force_path", 0)
+            e.count_filtered(st1)
+            o1 = oracle.OracleTable(k, 1 << 12).load_filter(flo, fhi).count_reads_filtered(parent[:1000])
+            np.testing.assert_array_equal(e.query(lo, hi), o1.query(lo, hi))
