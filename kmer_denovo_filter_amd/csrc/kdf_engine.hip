@@ -222,6 +222,51 @@ __global__ __launch_bounds__(256) void kdf_export_kernel(
     }
 }
 
+// dump -L into device buffers, narrow keys, min_count >= 1: ONE read of the table.  A wave takes 16 rows of 64 slots;
+// all 32 loads (keys + counts) are issued before anything is used, the kept entries are counted with ballots, the
+// wave reserves its output range with one atomic and writes.  (The two-phase kernel above reads the counts twice and
+// runs at half the memory rate; it stays for wide keys, min_count = 0 and the owner-grouped dump.)
+#define KDF_EXPORT1_ROWS 16
+#define KDF_EXPORT1_THREADS 1024
+__global__ __launch_bounds__(KDF_EXPORT1_THREADS) void kdf_export1_kernel(KdfTable t, uint32_t min_count, KdfCtl *ctl, uint64_t *__restrict__ olo,
+                                                                         uint32_t *__restrict__ ocnt, uint64_t out_cap)
+{
+    // one atomic per WORKGROUP (16 K slots): a same-address returning atomic per wave was what bounded the dump
+    __shared__ uint32_t wtot[KDF_EXPORT1_THREADS / 64];
+    __shared__ unsigned long long wg_base;
+    const uint64_t cap = 1ull << t.log2cap;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t wave = (uint64_t)blockIdx.x * (KDF_EXPORT1_THREADS / 64) + wv;
+    const uint64_t first = wave * (KDF_EXPORT1_ROWS * 64);
+    uint64_t lo[KDF_EXPORT1_ROWS]; uint32_t c[KDF_EXPORT1_ROWS];
+#pragma unroll
+    for (int r = 0; r < KDF_EXPORT1_ROWS; ++r) {
+        const uint64_t i = first + (uint64_t)r * 64 + lane;
+        const bool in = i < cap;
+        c[r] = in ? t.cnt[i] : 0u;
+        lo[r] = in ? t.lo[i] : KDF_EMPTY;
+    }
+    unsigned long long kb[KDF_EXPORT1_ROWS]; uint32_t tot = 0;
+#pragma unroll
+    for (int r = 0; r < KDF_EXPORT1_ROWS; ++r) { kb[r] = __ballot(c[r] >= min_count && lo[r] != KDF_EMPTY); tot += (uint32_t)__popcll(kb[r]); }
+    if (lane == 0) wtot[wv] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int i = 0; i < KDF_EXPORT1_THREADS / 64; ++i) { const uint32_t v = wtot[i]; wtot[i] = acc; acc += v; }
+        wg_base = acc ? atomicAdd(&ctl->cursor, (unsigned long long)acc) : 0ull;
+    }
+    __syncthreads();
+    unsigned long long base = wg_base + wtot[wv];
+#pragma unroll
+    for (int r = 0; r < KDF_EXPORT1_ROWS; ++r) {
+        if ((kb[r] >> lane) & 1) {
+            const uint64_t pos = base + __popcll(kb[r] & ((1ull << lane) - 1));
+            if (pos < out_cap) { olo[pos] = lo[r]; if (ocnt) ocnt[pos] = c[r]; }
+        }
+        base += __popcll(kb[r]);
+    }
+}
 
 // ---------------------------------------------------------------------------
 // count --if through a membership sieve.  In the parent-filter / VCF stages almost every window MISSES the filter
@@ -1591,7 +1636,11 @@ static int export_pass(kdf_engine *h, uint32_t min_count, bool write, uint64_t *
     }
     const uint64_t waves = (h->cap + KDF_EXPORT_ROWS * 64 - 1) / (KDF_EXPORT_ROWS * 64);
     const unsigned blocks = (unsigned)((waves + 3) / 4);
-    if (h->kw == 1) {
+    if (h->kw == 1 && write && !parts && min_count >= 1) {
+        const uint64_t w1 = (h->cap + KDF_EXPORT1_ROWS * 64 - 1) / (KDF_EXPORT1_ROWS * 64);
+        const unsigned wpb = KDF_EXPORT1_THREADS / 64;
+        hipLaunchKernelGGL(kdf_export1_kernel, dim3((unsigned)((w1 + wpb - 1) / wpb)), dim3(KDF_EXPORT1_THREADS), 0, h->stream, h->t, min_count, h->ctl, olo, ocnt, out_cap);
+    } else if (h->kw == 1) {
         if (write) hipLaunchKernelGGL((kdf_export_kernel<1, true>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap, parts);
         else hipLaunchKernelGGL((kdf_export_kernel<1, false>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap, parts);
     } else {
