@@ -32,46 +32,48 @@ BATCH_BASES = 1 << 27
 
 
 def _format_elapsed(seconds):
-    if seconds < 60:
-        return f"{seconds:.1f}s"
-    if seconds < 3600:
-        return f"{int(seconds // 60)}m {seconds % 60:.1f}s"
-    return f"{int(seconds // 3600)}h {int((seconds % 3600) // 60)}m {seconds % 60:.0f}s"
+    """``12.3s`` / ``4m 5.0s`` / ``1h 2m 3s``: the strings of the reference's progress log."""
+    minutes, sec = divmod(seconds, 60)
+    if minutes < 1:
+        return "%.1fs" % seconds
+    hours, minutes = divmod(int(minutes), 60)
+    return "%dh %dm %.0fs" % (hours, minutes, sec) if hours else "%dm %.1fs" % (minutes, sec)
+
+
+_SIZE_UNITS = ("B", "KB", "MB", "GB", "TB", "PB")
 
 
 def _format_file_size(path):
+    """Size of a file in powers of 1024 with one decimal (``?`` when it cannot be read)."""
     try:
-        size = os.path.getsize(path)
+        size = float(os.path.getsize(path))
     except OSError:
         return "?"
-    for unit in ("B", "KB", "MB", "GB", "TB"):
-        if size < 1024:
-            return f"{size:.1f} {unit}"
+    step = 0
+    while size >= 1024 and step < len(_SIZE_UNITS) - 1:
         size /= 1024
-    return f"{size:.1f} PB"
+        step += 1
+    return "%.1f %s" % (size, _SIZE_UNITS[step])
 
 
 def _find_jf_files(base_path):
-    """Existing ``base.jf`` / ``base.jf_N`` files (reference :59-70).  The engine
-    never overflows into chunk files, so this is at most one file."""
-    files = []
-    if os.path.exists(base_path):
-        files.append(base_path)
-    files.extend(sorted(glob.glob(base_path + "_[0-9]*")))
-    return files
+    """``base.jf`` when it exists, then its overflow chunks ``base.jf_N`` in name order (reference :59-70:
+    Jellyfish spills such chunks when its table is too small; the engine grows in HBM and never does, but an
+    index a user built with Jellyfish may come in pieces)."""
+    chunks = sorted(glob.glob(glob.escape(base_path) + "_[0-9]*"))
+    return ([base_path] if os.path.exists(base_path) else []) + chunks
 
 
 def _estimate_jf_hash_size(bam_path, kmer_size, default="1G"):
-    """Same heuristic and string format as the reference (:73-107)."""
+    """The reference's ``-s`` heuristic (:73-107): 0.3 table entries per BAM byte, held between 100 M and 4 G,
+    printed in whole G from 10^9 entries on, else in whole M."""
     try:
-        file_size = os.path.getsize(bam_path)
+        entries = os.path.getsize(bam_path) * 3 // 10
     except OSError:
         return default
-    estimated_distinct = (file_size * 3) // 10
-    entries = max(100_000_000, min(estimated_distinct, 4_000_000_000))
-    if entries >= 1_000_000_000:
-        return f"{entries // 1_000_000_000}G"
-    return f"{entries // 1_000_000}M"
+    entries = min(max(entries, 100_000_000), 4_000_000_000)
+    unit, div = ("G", 10**9) if entries >= 10**9 else ("M", 10**6)
+    return "%d%s" % (entries // div, unit)
 
 
 def _parse_hash_size(s, default=1 << 20):

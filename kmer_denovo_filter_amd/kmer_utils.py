@@ -25,13 +25,12 @@ _COMP = str.maketrans("ACGTacgt", "TGCAtgca")
 
 def reverse_complement(seq):
     """Reverse complement (case preserved), reference :30-32."""
-    return seq.translate(_COMP)[::-1]
+    return seq[::-1].translate(_COMP)
 
 
 def canonicalize(kmer):
     """Lexicographically smaller of a k-mer and its reverse complement, reference :35-38."""
-    rc = kmer.translate(_COMP)[::-1]
-    return kmer if kmer < rc else rc
+    return min(kmer, reverse_complement(kmer))
 
 
 def _is_symbolic(allele):
@@ -105,22 +104,17 @@ def extract_variant_spanning_kmers(read, variant_pos, k, min_baseq=0, ref=None, 
 
 
 def _extract_read_kmers(seq, kmer_size):
-    """(canon_at_pos, unique_candidates), reference :91-121: upper-cased read,
-    windows holding 'N' skipped, first-seen order."""
-    seq_len = len(seq)
-    if seq_len < kmer_size:
+    """(canon_at_pos, unique_candidates) as the reference builds them (:91-121): the read is upper-cased, a
+    window holding an 'N' yields nothing, candidates keep first-seen order.  The N test is one running sum
+    over the read instead of a substring search per window."""
+    n_windows = len(seq) - kmer_size + 1
+    if n_windows <= 0:
         return {}, []
-    seq_upper = seq.upper()
-    canon_at_pos = {}
-    candidates = []
-    for i in range(seq_len - kmer_size + 1):
-        kmer = seq_upper[i:i + kmer_size]
-        if "N" in kmer:
-            continue
-        canon = canonicalize(kmer)
-        canon_at_pos[i] = canon
-        candidates.append(canon)
-    return canon_at_pos, list(dict.fromkeys(candidates))
+    upper = seq.upper()
+    n_before = np.concatenate(([0], np.cumsum(np.frombuffer(upper.encode(), dtype=np.uint8) == ord("N"))))
+    clean = np.flatnonzero(n_before[kmer_size:] == n_before[:n_windows])          # window starts without an N
+    canon_at_pos = {int(i): canonicalize(upper[i:i + kmer_size]) for i in clean.tolist()}
+    return canon_at_pos, list(dict.fromkeys(canon_at_pos.values()))
 
 
 class KmerAutomaton:
