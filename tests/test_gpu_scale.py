@@ -36,27 +36,6 @@ def test_binned_vs_direct_vs_oracle_midsize(oracle):
         np.testing.assert_array_equal(cnt, ocnt)
 
 
-def test_full_size_paths_agree_and_conserve():
-    """10 M x 150 bp: sum of counts == valid windows; binned == direct."""
-    import torch
-    from kmer_denovo_filter_amd import KmerEngine
-    ds = _dev_stream(10_000_000)
-    out = []
-    for path in (2, 1):
-        with KmerEngine(31, capacity_hint=1 << 27) as e:
-            e.set_option("force_path", path)
-            e.count_dev(ds.packed.data_ptr(), ds.invalid.data_ptr(), ds.n_bases)
-            cap, distinct, windows = e.stats()
-            lo, hi, cnt = e.export_ge(0)
-            assert len(lo) == distinct
-            assert int(cnt.astype(np.uint64).sum()) == windows
-            assert (np.diff(lo.astype(np.uint64)) > 0).all()          # sorted, no duplicates
-            out.append((lo, cnt, windows))
-    np.testing.assert_array_equal(out[0][0], out[1][0])
-    np.testing.assert_array_equal(out[0][1], out[1][1])
-    assert out[0][2] == out[1][2]
-
-
 def test_parent_filter_chain_synthetic_trio(oracle):
     """BASELINE configs[2] at reduced size (1 Mbp genome, 20x): the surviving
     proband-unique SET equals the oracle's discovery chain on the same reads."""
