@@ -407,6 +407,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_finesort_kernel(KbPlan plan, Kb
     unsigned long long &sh_start = *(unsigned long long *)(wsum + 32);
     uint32_t &sh_len = *(uint32_t *)(wsum + 34);
     const uint64_t chunk = blockIdx.x;
+    if (chunk >= s.totals[1]) return;                       // the grid covers the largest possible number of chunks
     if (threadIdx.x == 0) {
         // locate the coarse bin of this chunk: chunk_first is ascending
         const int nb = 1 << plan.c1;

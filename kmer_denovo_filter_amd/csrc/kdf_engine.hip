@@ -321,25 +321,30 @@ __global__ __launch_bounds__(KB_THREADS) void kdf_sieve_count_kernel(
         const uint64_t tile = (slab0 + sl) * TILES_PER_SLAB + threadIdx.x / TPT;
         KbWindows<KW> win;
         win.load(packed, invalid, tile, n_tiles, threadIdx.x % TPT, k);
-        uint64_t klo[WPT], khi[KW == 2 ? WPT : 1], w[WPT], bits[WPT];
-#pragma unroll
-        for (int u = 0; u < WPT; ++u) {                         // WPT sieve words in flight per lane
-            uint64_t lo, hi; win.key(u, lo, hi);
-            klo[u] = lo; if constexpr (KW == 2) khi[u] = hi;
-            uint64_t wi;
-            kdf_sieve_bits(kdf_hash(lo, hi), sv.wmask, wi, bits[u]);
-            w[u] = sv.words[wi];
-        }
         nwin += __popc(win.valid);
+        // eight sieve words in flight per lane; only the word and 12 hash bits are kept per window (the key of a
+        // survivor is taken again from the registers that hold the stream), so eight waves fit a SIMD
+        constexpr int HB = WPT < 8 ? WPT : 8;
 #pragma unroll
-        for (int u = 0; u < WPT; ++u) {
-            const bool ok = ((win.valid >> u) & 1) && (w[u] & bits[u]) == bits[u];
-            const unsigned long long mk = __ballot(ok);
-            if (mk) {
-                const uint32_t at = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-                if (ok) { wqlo[at] = klo[u]; if constexpr (KW == 2) wqhi[at] = khi[u]; }
-                wq_n += (uint32_t)__popcll(mk);
-                if (wq_n >= 64) { wq_n -= 64; drain(wq_n, 64); }            // (wave-uniform)
+        for (int u0 = 0; u0 < WPT; u0 += HB) {
+            uint64_t w[HB]; uint32_t hb[HB];
+#pragma unroll
+            for (int u = 0; u < HB; ++u) {
+                uint64_t lo, hi; win.key(u0 + u, lo, hi);
+                const uint64_t hsh = kdf_hash(lo, hi);
+                hb[u] = (uint32_t)hsh & 0xFFFu;
+                w[u] = sv.words[(hsh >> 12) & sv.wmask];
+            }
+#pragma unroll
+            for (int u = 0; u < HB; ++u) {
+                const bool ok = ((win.valid >> (u0 + u)) & 1) && (((w[u] >> (hb[u] & 63)) & (w[u] >> (hb[u] >> 6)) & 1ull) != 0);
+                const unsigned long long mk = __ballot(ok);
+                if (mk) {
+                    const uint32_t at = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                    if (ok) { uint64_t lo, hi; win.key(u0 + u, lo, hi); wqlo[at] = lo; if constexpr (KW == 2) wqhi[at] = hi; }
+                    wq_n += (uint32_t)__popcll(mk);
+                    if (wq_n >= 64) { wq_n -= 64; drain(wq_n, 64); }        // (wave-uniform)
+                }
             }
         }
     }
@@ -394,6 +399,7 @@ struct kdf_engine {
     uint32_t opt_binned_filtered_min_log2cap = 23;   // count --if goes binned from 2^23 slots (measured crossover)
     int opt_force_path = 0;                          // 0 auto, 1 direct, 2 binned, 3 super-k-mer (kdf_sk.h)
     uint32_t opt_sk_min_k = 20;                      // auto (option sk_auto): narrow keys from this k on take the super-k-mer path
+    int opt_sieve_bits = 0;                          // sieve bits per filter key (0: 32 up to 2^20 keys, 16 beyond)
     int opt_sk_auto = 0;                             // 0: the super-k-mer path only when forced (it is at parity with the binned path)
     // super-k-mer path (kdf_sk.h): scratch, device counters + pinned mirror, overflow table bookkeeping
     void *sk_buf[16] = {nullptr};
@@ -701,8 +707,11 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     const size_t lds_c = ((size_t)8 * KW + 4) * ((size_t)1 << plan.bucket_bits) + (2 + 32 + KB_C_RUNS) * 4 + (size_t)KB_C_RUNS * 8
                          + (KW == 2 ? (size_t)KB_C_RUNS * 4 : 0);                           // wide: run_hi
     const size_t lds_a1 = (size_t)(SLAB + 2) * 8 * KW + (size_t)nb1 * 16 + (size_t)(2 * (nb1 + 32) + 32) * 4;
-    int rc = kb_set_lds_attrs<KW>(h, lds_a1, lds_b, lds_c);
-    if (rc) return rc;
+    int rc = KDF_OK;
+    if (!h->sk_attrs_set[2 + KW]) {                           // once per engine (ten hipFuncSetAttribute calls)
+        if ((rc = kb_set_lds_attrs<KW>(h, lds_a1, lds_b, lds_c))) return rc;
+        h->sk_attrs_set[2 + KW] = true;
+    }
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     std::vector<hipEvent_t> sev;
@@ -726,14 +735,14 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     hipLaunchKernelGGL(kb_scan1_kernel, dim3(1), dim3(KB_THREADS), 0, h->stream, plan, s, (uint32_t)CHUNK, h->ctl);
     HIPCHK(h, hipGetLastError());
     stamp();                                                   // end of A0 (+ scans)
-    HIPCHK(h, hipMemcpyAsync(h->kb_totals_host, s.totals, 32, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    const uint64_t n_entries = h->kb_totals_host[0], n_chunks = h->kb_totals_host[1];
-    if (n_entries == 0) { if (h->prof) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); for (hipEvent_t e : sev) (void)hipEventDestroy(e); } return KDF_OK; }
+    // No host round trip here: the entry buffer is sized for one entry per position and B is launched over the
+    // largest number of chunks the bins can have (its workgroups beyond the real count leave at once).
+    const uint64_t n_entries_max = n_tiles * KDF_TILE;
+    const uint64_t n_chunks_max = n_entries_max / CHUNK + (uint64_t)nbins + 1;
 
     const uint64_t nb_table = 1ull << (plan.c1 + plan.c2 + plan.sub_bits);
-    if ((rc = kb_reserve(h, 0, n_entries * 8 * KW))) return rc;             // wide: 16-byte (lo, hi) entries
-    if ((rc = kb_reserve(h, 2, n_chunks * (size_t)plan.off_stride * 4))) return rc;
+    if ((rc = kb_reserve(h, 0, n_entries_max * 8 * KW))) return rc;         // wide: 16-byte (lo, hi) entries
+    if ((rc = kb_reserve(h, 2, n_chunks_max * (size_t)plan.off_stride * 4))) return rc;
     const size_t failed_bytes = (size_t)((nb_table + 31) / 32) * 4;
     if ((rc = kb_reserve(h, 3, failed_bytes))) return rc;
     s.ent_lo = (uint64_t *)h->kb_buf[0];
@@ -743,7 +752,7 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     if (sliced) hipLaunchKernelGGL((kb_scatter1_kernel<KW, true>), dim3(grid_a), dim3(KB_THREADS), lds_a1, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
     else hipLaunchKernelGGL((kb_scatter1_kernel<KW, false>), dim3(grid_a), dim3(KB_THREADS), lds_a1, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
     stamp();                                                   // end of A1
-    hipLaunchKernelGGL(kb_finesort_kernel<KW>, dim3((unsigned)n_chunks), dim3(KB_THREADS), lds_b, h->stream, plan, s);
+    hipLaunchKernelGGL(kb_finesort_kernel<KW>, dim3((unsigned)n_chunks_max), dim3(KB_THREADS), lds_b, h->stream, plan, s);
     stamp();                                                   // end of B
     if (filtered && (rc = materialize(h))) return rc;
     // narrow keys: lookahead + wave-queue variant of kernel C (debug flag 8 selects the plain loop, for A/B runs)
@@ -781,6 +790,7 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     // that even if every entry of the failed buckets were new the load stays
     // <= 0.5, then replay exactly those buckets through the global-atomic path.
     h->stat_replayed_buckets += n_failed;
+    const uint64_t n_entries = h->kb_totals_host[0];
     const uint64_t worst = h->distinct + std::min<uint64_t>(n_entries, n_failed * ((n_entries / std::max<uint64_t>(nb_table, 1)) * 4 + 4096));
     uint32_t want = std::max<uint32_t>(h->t.log2cap + 1, cap_log2_for(worst));
     if ((rc = table_rehash(h, want))) return rc;
@@ -1267,7 +1277,7 @@ static int count_filtered_dev(kdf_engine *h, const uint64_t *d_packed, const uin
         h->last_path = 3;
         return KDF_OK;
     }
-    if (h->opt_force_path == 4) return fail(h, KDF_ERR_STATE, "force_path 4 (sieve): no sieve for this filter (more than 2^27 keys, or keys were added after kdf_load_filter)");
+    if (h->opt_force_path == 4) return fail(h, KDF_ERR_STATE, "force_path 4 (sieve): no sieve for this filter (it would not fit the caches, or keys were added after kdf_load_filter)");
     if (use_binned(h, n_bases, true)) { h->last_path = 1; return kb_passes(h, d_packed, d_invalid, n_bases, true); }
     h->last_path = 0;
     launch_stream<MODE_FILTERED>(h, d_packed, d_invalid, 0, n_tiles, nullptr);
@@ -1454,11 +1464,16 @@ static int load_filter_core(kdf_engine *h, const uint64_t *d_lo, const uint64_t 
         if ((rc = ctl_sync(h, &full))) return rc;
         if (full) return fail(h, KDF_ERR_TABLE_FULL, "kdf_load_filter: bucket overflow");
     }
-    // the membership sieve over the same keys: 32 bits per key up to 2^20 keys, 16 beyond (it should live in L2 /
-    // the Infinity Cache); none past 2^27 keys
+    // The membership sieve over the same keys.  Every window costs one random 8-byte read of it, i.e. one L2 request:
+    // measured on the parent-filter workload (1.49 G windows, 1.9 M keys) 8.3 ms with a 2 MB sieve, 9.1 ms with 4 MB,
+    // 16 ms with 8 MB, 24 ms with 16 MB -- it must sit in the 4 MB L2 of every XCD beside the streamed reads.  So:
+    // the most bits per key out of 32 / 16 / 8 that keep it within 2 MB, 8 bits per key beyond that, and no sieve
+    // (the binned path) once even that passes 16 MB.
     h->sieve_valid = false;
-    if (n <= (1ull << 27)) {
-        const uint64_t bits = n * (n <= (1ull << 20) ? 32 : 16);
+    uint64_t bpk = h->opt_sieve_bits ? (uint64_t)h->opt_sieve_bits : 32;
+    if (!h->opt_sieve_bits) while (bpk > 8 && n * bpk > (16ull << 20)) bpk >>= 1;
+    if (h->opt_sieve_bits || n * bpk <= (128ull << 20)) {
+        const uint64_t bits = n * bpk;
         const uint64_t words = std::max<uint64_t>(1024, 1ull << log2ceil((bits + 63) / 64));
         if (h->sieve_alloc < words) {
             if (h->sieve) (void)hipFree(h->sieve);
@@ -1891,6 +1906,7 @@ int kdf_set_option(kdf_engine *h, const char *name, int64_t value) {
     else if (n == "sk_min_k") h->opt_sk_min_k = (uint32_t)value;
     else if (n == "sk_balance") h->opt_sk_balance = (int)value;
     else if (n == "sk_auto") h->opt_sk_auto = (int)value;
+    else if (n == "sieve_bits") h->opt_sieve_bits = (int)value;
     else if (n == "debug_flags") h->opt_debug_flags = (uint32_t)value;
     else return fail(h, KDF_ERR_INVALID, "kdf_set_option: unknown option %s", name);
     return KDF_OK;
