@@ -90,7 +90,17 @@ struct KbScratch {
     uint32_t *chunk_off;            // [n_chunks][2^c2 + 1]
     uint32_t *failed;               // bitmap over TABLE buckets (2^(c1+c2+sub_bits) bits)
     uint64_t *ent_lo;               // entries (keys); wide keys: an array of (lo, hi) pairs, 16 B each (kb_ent2)
+    // pool variant of the scatter (kb_scatter2_kernel): no histogram pass, the runs go to 4 KB chunks taken from a pool
+    uint64_t *pool;                 // [max_chunks][KB_PCH entries]
+    uint32_t *chunk_bin, *chunk_pos, *chunk_fill, *chunk_list;   // [max_chunks]
+    uint32_t *bin_nchunks;          // [2^c1]
+    uint32_t *bin_chunk_start;      // [2^c1 + 1]
+    uint32_t *pool_ctr;             // [0] chunks taken
+    uint32_t max_chunks, pad2;
 };
+#define KB_GROUP 32                                  // pool chunks per fine-sort group
+#define KB_PCH(KW) (KbCfg<KW>::CHUNK / KB_GROUP)     // entries per pool chunk: 4 KB for either key width
+#define KB_NOCHUNK 0xFFFFFFFFu
 
 __device__ __forceinline__ uint32_t kb_coarse(const KbPlan &p, uint64_t h) {
     return p.c1 ? (uint32_t)(h >> (64 - p.c1)) : 0u;
@@ -469,6 +479,248 @@ __global__ __launch_bounds__(KB_THREADS) void kb_finesort_kernel(KbPlan plan, Kb
             // streams than on 16-byte entries (measured: 15.5 vs 17.0 ms at k = 63)
             const KbEnt2 v = s2[i];
             s.ent_lo[2 * start + i] = v.lo; s.ent_lo[2 * start + len + i] = v.hi;
+        } else s.ent_lo[start + i] = slo[i];
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// A1 without A0.  The histogram pass existed only to give every (workgroup, bin) run an exact place in a contiguous
+// bin.  Here a workgroup writes its runs of a bin into 4 KB chunks it takes from a global pool (one thread per bin
+// takes the chunks a slab needs, all bins at once, next to the scan), so one pass over the stream is enough; the
+// fine sort then works on groups of KB_GROUP chunks of one bin (kb_poolscan / kb_chunklist / kb_finesort2 below) and
+// leaves the arrays kernel C reads -- chunk_first, bin_start, chunk_off, ent_lo -- with the meaning they always had
+// (a "chunk" of C is a group: bin_start[c] = chunk_first[c] * CHUNK, so chunk j of the bins starts at j * CHUNK).
+// (the kernel takes only the pointers it needs: the whole KbScratch costs ~40 SGPRs that spill into VGPR lanes,
+// and this kernel sits at the 128-VGPR limit of a 1024-thread workgroup)
+struct KbPool { uint64_t *pool; uint32_t *chunk_bin, *chunk_pos, *chunk_fill, *bin_nchunks, *pool_ctr; uint32_t max_chunks, c1, key_parts, key_part; };
+template <int KW, bool SLICED>
+__global__ __launch_bounds__(KB_THREADS) void kb_scatter2_kernel(
+    const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid, uint64_t n_tiles, int k,
+    KbPool s, uint32_t slabs_per_wg, KdfCtl *ctl)
+{
+    KbPlan plan{}; plan.c1 = s.c1; plan.key_parts = s.key_parts; plan.key_part = s.key_part;
+    constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT, SLAB = KB_THREADS * WPT, PCH = KB_PCH(KW);
+    constexpr uint32_t TILES_PER_SLAB = KB_THREADS / TPT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t *slo = (uint64_t *)smem;                                   // [SLAB + 1]: last = trash slot
+    KbEnt2 *s2 = (KbEnt2 *)smem;
+    KbEnt2 *const pool2 = (KbEnt2 *)s.pool;
+    uint32_t *cur_chunk = (uint32_t *)(smem + (size_t)(SLAB + 2) * 8 * KW);   // [bins] this workgroup's open chunk of the bin
+    uint32_t *cur_fill = cur_chunk + (1 << KB_C1_MAX);                  // [bins]
+    uint32_t *nxt = cur_fill + (1 << KB_C1_MAX);                        // [bins] first of the chunks taken for the bin this slab
+    uint32_t *hist = nxt + (1 << KB_C1_MAX);                            // [bins + 1]: last = dummy counter of invalid windows
+    uint32_t *offs = hist + (1 << KB_C1_MAX) + 32;                      // [bins + 1]: offs[DUMMY] = trash slot
+    constexpr int DUMMY = 1 << KB_C1_MAX;
+    const int nb = 1 << plan.c1;
+    if (threadIdx.x == 0) { hist[DUMMY] = 0; offs[DUMMY] = (uint32_t)SLAB; }
+    for (int i = threadIdx.x; i < nb; i += KB_THREADS) { hist[i] = 0; cur_chunk[i] = KB_NOCHUNK; cur_fill[i] = 0; }
+    __syncthreads();
+    const uint64_t slab0 = (uint64_t)blockIdx.x * slabs_per_wg;
+    constexpr int GL = 2 * WPT;                                         // lanes that copy one bin's run = its mean length
+    const int grp = threadIdx.x / GL, lane_g = threadIdx.x % GL;
+    constexpr int NGRP = KB_THREADS / GL;
+    unsigned long long nwin = 0;
+    KbWindows<KW> win;
+    if (slab0 * TILES_PER_SLAB < n_tiles)
+        win.load(packed, invalid, slab0 * TILES_PER_SLAB + threadIdx.x / TPT, n_tiles, threadIdx.x % TPT, k);
+    for (uint32_t sl = 0; sl < slabs_per_wg; ++sl) {
+        if ((slab0 + sl) * TILES_PER_SLAB >= n_tiles) break;          // uniform
+        KbWindows<KW> nx;
+        {
+            const bool more = sl + 1 < slabs_per_wg;
+            nx.issue(packed, invalid, more ? (slab0 + sl + 1) * TILES_PER_SLAB + threadIdx.x / TPT : n_tiles,
+                     n_tiles, threadIdx.x % TPT, k);
+        }
+        uint64_t klo[WPT], khi[KW == 2 ? WPT : 1];
+        uint32_t br[WPT];                       // bin << 16 | rank
+#pragma unroll
+        for (int u = 0; u < WPT; ++u) {
+            uint64_t lo, hi; win.key(u, lo, hi);
+            klo[u] = lo; if constexpr (KW == 2) khi[u] = hi;
+            const uint64_t hsh = kdf_hash(lo, hi);
+            const bool ok = ((win.valid >> u) & 1) && (!SLICED || kdf_slice(hsh, plan.key_parts) == plan.key_part);
+            br[u] = (ok ? kb_coarse(plan, hsh) : (uint32_t)DUMMY) << 16;
+        }
+#pragma unroll
+        for (int u = 0; u < WPT; ++u) br[u] |= atomicAdd(&hist[br[u] >> 16], 1u) & 0xFFFFu;
+        kb_lds_barrier();                                               // B1: all ranks taken
+        if (threadIdx.x < 64) {
+            const int per = (nb + 63) >> 6;
+            const int b0 = threadIdx.x * per;
+            uint32_t sum = 0;
+            for (int i = 0; i < per; ++i) sum += (b0 + i < nb) ? hist[b0 + i] : 0;
+            uint32_t inc = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if ((int)threadIdx.x >= o) inc += t; }
+            uint32_t run = inc - sum;
+            for (int i = 0; i < per; ++i) if (b0 + i < nb) { offs[b0 + i] = run; run += hist[b0 + i]; }
+            if (threadIdx.x == 63) nwin += inc;                         // the slab's valid windows (lane 63 holds the total)
+        }
+        kb_lds_barrier();                                               // B2: offsets ready
+        {
+            uint32_t pos[WPT];
+#pragma unroll
+            for (int u = 0; u < WPT; ++u) {
+                const uint32_t bin = br[u] >> 16;
+                pos[u] = offs[bin] + ((bin == (uint32_t)DUMMY) ? 0u : (br[u] & 0xFFFF));
+            }
+#pragma unroll
+            for (int u = 0; u < WPT; ++u) {
+                if constexpr (KW == 2) s2[pos[u]] = KbEnt2{klo[u], khi[u]};
+                else slo[pos[u]] = klo[u];
+            }
+        }
+        nx.finish();
+        asm volatile("" :: "v"(nx.e[0]), "v"(nx.e[1]), "v"(nx.valid));
+        // a thread per bin takes the chunks the bin's run needs beyond its open chunk: two independent atomics, all bins
+        // at once -- after the LDS scatter, when the slab's keys no longer occupy the registers (the kernel sits at the
+        // 128-VGPR limit of a 1024-thread workgroup).  The pool holds one entry per stream position plus every
+        // workgroup's open chunks: it cannot run out.
+        for (int bin = (int)threadIdx.x; bin < nb; bin += KB_THREADS) {
+            const uint32_t n = hist[bin], ch = cur_chunk[bin];
+            const uint32_t room = ch == KB_NOCHUNK ? 0u : (uint32_t)PCH - cur_fill[bin];
+            uint32_t id0 = KB_NOCHUNK;
+            if (n > room) {
+                const uint32_t need = (n - room + PCH - 1) / PCH;
+                id0 = atomicAdd(&s.pool_ctr[0], need);
+                const uint32_t pos0 = atomicAdd(&s.bin_nchunks[bin], need);
+                for (uint32_t q = 0; q < need; ++q) if (id0 + q < s.max_chunks) { s.chunk_bin[id0 + q] = (uint32_t)bin; s.chunk_pos[id0 + q] = pos0 + q; }
+            }
+            nxt[bin] = id0;
+        }
+        kb_lds_barrier();                                               // B3: sorted image complete, chunks taken
+        for (int bin = grp; bin < nb; bin += NGRP) {
+            const uint32_t n = hist[bin], o = offs[bin];
+            if (n == 0) continue;
+            uint32_t ch = cur_chunk[bin], fl = cur_fill[bin], nxc = nxt[bin], done = 0;
+            while (done < n) {
+                if (ch == KB_NOCHUNK || fl == (uint32_t)PCH) {
+                    if (lane_g == 0 && ch != KB_NOCHUNK && ch < s.max_chunks) s.chunk_fill[ch] = PCH;
+                    ch = nxc++; fl = 0;
+                }
+                const uint32_t take = min(n - done, (uint32_t)PCH - fl);
+                if (ch < s.max_chunks) {
+                    const size_t dst = (size_t)ch * PCH + fl;
+                    for (uint32_t i = lane_g; i < take; i += GL) {
+                        if constexpr (KW == 2) pool2[dst + i] = s2[o + done + i];
+                        else s.pool[dst + i] = slo[o + done + i];
+                    }
+                }
+                done += take; fl += take;
+            }
+            if (lane_g == 0) { cur_chunk[bin] = ch; cur_fill[bin] = fl; hist[bin] = 0; }
+        }
+        if (threadIdx.x == 0) hist[DUMMY] = 0;
+        kb_lds_barrier();                                               // B4: hist is zero, image free
+        win = nx;
+    }
+    for (int i = threadIdx.x; i < nb; i += KB_THREADS) {
+        const uint32_t ch = cur_chunk[i];
+        if (ch != KB_NOCHUNK && ch < s.max_chunks) s.chunk_fill[ch] = cur_fill[i];
+    }
+    if (threadIdx.x == 63 && nwin) atomicAdd(&ctl->windows[(blockIdx.x % KDF_SHARDS) * 16], nwin);
+}
+
+// bins -> chunk lists, groups of KB_GROUP chunks; leaves chunk_first / bin_start as kernel C reads them
+__global__ __launch_bounds__(KB_THREADS) void kb_poolscan_kernel(KbPlan plan, KbScratch s, uint32_t chunk_entries) {
+    __shared__ uint32_t a[(1 << KB_C1_MAX) + 1];
+    __shared__ unsigned long long g[(1 << KB_C1_MAX) + 1];
+    const int nb = 1 << plan.c1;
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0; unsigned long long gacc = 0;
+        for (int i = 0; i < nb; ++i) {
+            a[i] = acc; g[i] = gacc;
+            const uint32_t n = s.bin_nchunks[i];
+            acc += n; gacc += (n + KB_GROUP - 1) / KB_GROUP;
+        }
+        a[nb] = acc; g[nb] = gacc;
+        s.totals[0] = (unsigned long long)acc * (chunk_entries / KB_GROUP); s.totals[1] = gacc; s.totals[2] = 0; s.totals[3] = 0; s.failed_flag[0] = 0;
+        for (int i = 9; i < 16; ++i) s.totals[i] = 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= nb; i += KB_THREADS) { s.bin_chunk_start[i] = a[i]; s.chunk_first[i] = g[i]; s.bin_start[i] = g[i] * chunk_entries; }
+}
+__global__ __launch_bounds__(256) void kb_chunklist_kernel(KbScratch s) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= min(s.pool_ctr[0], s.max_chunks)) return;
+    s.chunk_list[s.bin_chunk_start[s.chunk_bin[c]] + s.chunk_pos[c]] = c;
+}
+
+// B on groups of pool chunks: gather the group's entries, sort them by fine bin in LDS, write the sorted group to
+// ent_lo[group * CHUNK ...] (wide keys: lo words, then at + CHUNK the hi words) and its offset table
+template <int KW>
+__global__ __launch_bounds__(KB_THREADS) void kb_finesort2_kernel(KbPlan plan, KbScratch s)
+{
+    constexpr int CHUNK = KbCfg<KW>::CHUNK, EPT = CHUNK / KB_THREADS, PCH = KB_PCH(KW);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t *slo = (uint64_t *)smem;
+    KbEnt2 *s2 = (KbEnt2 *)smem;
+    const KbEnt2 *const pool2 = (const KbEnt2 *)s.pool;
+    uint32_t *hist = (uint32_t *)(smem + (size_t)CHUNK * 8 * KW);       // [KB_F]
+    uint32_t *offs = hist + KB_F;                                        // [KB_F]
+    uint32_t *wsum = offs + KB_F;                                        // [40]
+    uint32_t *cid = wsum + 40, *cfl = cid + KB_GROUP;                    // [KB_GROUP] chunk ids, fills
+    const uint64_t grp = blockIdx.x;
+    if (grp >= s.totals[1]) return;                                     // the grid covers the largest possible number of groups
+    const int nf = 1 << plan.c2;
+    for (int i = threadIdx.x; i < KB_F; i += KB_THREADS) hist[i] = 0;
+    if (threadIdx.x < KB_GROUP) {
+        const int nbn = 1 << plan.c1;
+        int lo = 0, hi = nbn;            // largest bin with chunk_first[bin] <= grp
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (s.chunk_first[mid] <= grp) lo = mid; else hi = mid; }
+        const uint32_t lc = s.bin_chunk_start[lo] + (uint32_t)(grp - s.chunk_first[lo]) * KB_GROUP + threadIdx.x;
+        const bool ok = lc < s.bin_chunk_start[lo + 1];
+        const uint32_t id = ok ? s.chunk_list[lc] : 0u;
+        cid[threadIdx.x] = id; cfl[threadIdx.x] = ok ? s.chunk_fill[id] : 0u;
+    }
+    __syncthreads();
+    uint64_t klo[EPT], khi[KW == 2 ? EPT : 1];
+    uint32_t br[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const uint32_t i = e * KB_THREADS + threadIdx.x, c = i / PCH, o = i % PCH;
+        br[e] = KB_NOCHUNK;
+        if (o < cfl[c]) {
+            const size_t src = (size_t)cid[c] * PCH + o;
+            if constexpr (KW == 2) { const KbEnt2 v = pool2[src]; klo[e] = v.lo; khi[e] = v.hi; }
+            else klo[e] = s.pool[src];
+            br[e] = 0;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        if (br[e] != KB_NOCHUNK) {
+            const uint32_t f = kb_fine(plan, kdf_hash(klo[e], KW == 2 ? khi[e] : 0));
+            br[e] = (f << 16) | atomicAdd(&hist[f], 1u);
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t v = threadIdx.x < nf ? hist[threadIdx.x] : 0;
+        uint32_t len = 0;
+        const uint32_t ex = kb_block_exscan(v, wsum, &len);
+        if (threadIdx.x < nf) { offs[threadIdx.x] = ex; s.chunk_off[grp * plan.off_stride + threadIdx.x] = ex; }
+        if (threadIdx.x == 0) { s.chunk_off[grp * plan.off_stride + nf] = len; wsum[39] = len; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        if (br[e] != KB_NOCHUNK) {
+            const uint32_t pos = offs[br[e] >> 16] + (br[e] & 0xFFFF);
+            if constexpr (KW == 2) s2[pos] = KbEnt2{klo[e], khi[e]};
+            else slo[pos] = klo[e];
+        }
+    }
+    __syncthreads();
+    const uint32_t len = wsum[39];
+    const uint64_t start = grp * (uint64_t)CHUNK;
+    for (uint32_t i = threadIdx.x; i < len; i += KB_THREADS) {
+        if constexpr (KW == 2) {
+            // chunk-local structure of arrays with a FIXED distance between a key's words (a group may be partly
+            // filled; kernel C takes min(entries left in the bin, CHUNK) as that distance, and bin_start makes it CHUNK)
+            const KbEnt2 v = s2[i];
+            s.ent_lo[2 * start + i] = v.lo; s.ent_lo[2 * start + CHUNK + i] = v.hi;
         } else s.ent_lo[start + i] = slo[i];
     }
 }

@@ -399,6 +399,10 @@ struct kdf_engine {
     uint32_t opt_binned_filtered_min_log2cap = 23;   // count --if goes binned from 2^23 slots (measured crossover)
     int opt_force_path = 0;                          // 0 auto, 1 direct, 2 binned, 3 super-k-mer (kdf_sk.h)
     uint32_t opt_sk_min_k = 20;                      // auto (option sk_auto): narrow keys from this k on take the super-k-mer path
+    int opt_binned_pool = 0;                         // binned path: 1 = pool scatter without the histogram pass (measured SLOWER: 6.4 ms
+                                                     // against A0 + A1 = 5.9 ms, the scatter sits at the 128-VGPR limit), 0 = A0 + A1 + B
+    void *kp_buf[8] = {nullptr};                     // pool variant: pool, chunk_bin, chunk_pos, chunk_fill, chunk_list, small, pool_ctr
+    size_t kp_bytes[8] = {0};
     int opt_sieve_bits = 0;                          // sieve bits per filter key (0: 32 up to 2^20 keys, 16 beyond)
     int opt_sk_auto = 0;                             // 0: the super-k-mer path only when forced (it is at parity with the binned path)
     // super-k-mer path (kdf_sk.h): scratch, device counters + pinned mirror, overflow table bookkeeping
@@ -717,14 +721,69 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     std::vector<hipEvent_t> sev;
     auto stamp = [&]() { if (h->prof) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, h->stream); sev.push_back(e); } };
     if (h->prof) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, h->stream); }
-    stamp();                                                   // start of A0
+    stamp();                                                   // start of A0 (pool variant: of the scatter)
+
+    const uint64_t nb_table = 1ull << (plan.c1 + plan.c2 + plan.sub_bits);
+    const size_t failed_bytes = (size_t)((nb_table + 31) / 32) * 4;
+    const int nbins = 1 << plan.c1;
+    if (h->opt_binned_pool) {
+        // ---- one pass over the stream: scatter into pool chunks, chunk lists, fine sort of chunk groups
+        constexpr int PCH = KB_PCH(KW);
+        const uint64_t n_slabs = (n_tiles + (KB_THREADS / TPT) - 1) / (KB_THREADS / TPT);
+        const uint32_t n_wg = (uint32_t)std::min<uint64_t>(n_slabs, (uint64_t)h->n_cu);       // one resident workgroup per CU (LDS)
+        const uint32_t slabs_per_wg = (uint32_t)((n_slabs + n_wg - 1) / n_wg);
+        const unsigned grid_a = (unsigned)((n_slabs + slabs_per_wg - 1) / slabs_per_wg);
+        const uint64_t max_chunks = n_tiles * KDF_TILE / PCH + (uint64_t)grid_a * nbins + 2;      // one entry per position + every open chunk
+        const uint64_t max_groups = max_chunks / KB_GROUP + nbins + 1;
+        if (max_chunks >= (1ull << 32)) return fail(h, KDF_ERR_INVALID, "binned pass: too many positions for one pass");
+        auto kp_reserve = [&](int i, size_t bytes) -> int {
+            if (h->kp_bytes[i] >= bytes) return KDF_OK;
+            if (h->kp_buf[i]) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->kp_buf[i]); h->kp_buf[i] = nullptr; h->kp_bytes[i] = 0; }
+            const size_t want = bytes + bytes / 16 + 4096;
+            HIPCHK(h, hipMalloc(&h->kp_buf[i], want));
+            h->kp_bytes[i] = want;
+            return KDF_OK;
+        };
+        if ((rc = kp_reserve(0, max_chunks * PCH * 8 * KW))) return rc;
+        for (int i = 1; i <= 4; ++i) if ((rc = kp_reserve(i, max_chunks * 4))) return rc;
+        if ((rc = kp_reserve(5, (size_t)(2 * nb1 + 8) * 4))) return rc;
+        if ((rc = kb_reserve(h, 0, max_groups * CHUNK * 8 * KW))) return rc;                       // sorted groups: what kernel C gathers from
+        if ((rc = kb_reserve(h, 2, max_groups * (size_t)plan.off_stride * 4))) return rc;
+        if ((rc = kb_reserve(h, 3, failed_bytes))) return rc;
+        s.pool = (uint64_t *)h->kp_buf[0];
+        s.chunk_bin = (uint32_t *)h->kp_buf[1]; s.chunk_pos = (uint32_t *)h->kp_buf[2];
+        s.chunk_fill = (uint32_t *)h->kp_buf[3]; s.chunk_list = (uint32_t *)h->kp_buf[4];
+        s.bin_nchunks = (uint32_t *)h->kp_buf[5]; s.bin_chunk_start = s.bin_nchunks + nb1; s.pool_ctr = s.bin_chunk_start + nb1 + 1;
+        s.max_chunks = (uint32_t)max_chunks;
+        s.ent_lo = (uint64_t *)h->kb_buf[0];
+        s.chunk_off = (uint32_t *)h->kb_buf[2]; s.failed = (uint32_t *)h->kb_buf[3];
+        HIPCHK(h, hipMemsetAsync(s.bin_nchunks, 0, (size_t)(2 * nb1 + 8) * 4, h->stream));
+        HIPCHK(h, hipMemsetAsync(s.failed, 0, failed_bytes, h->stream));
+        const size_t lds_a2 = (size_t)(SLAB + 2) * 8 * KW + (size_t)(3 * nb1 + 2 * (nb1 + 32)) * 4;
+        const size_t lds_b2 = (size_t)CHUNK * 8 * KW + (size_t)(2 * KB_F + 40 + 2 * KB_GROUP) * 4 + 16;
+        if (!h->sk_attrs_set[4 + KW]) {
+            HIPCHK(h, hipFuncSetAttribute((const void *)(kb_scatter2_kernel<KW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a2));
+            HIPCHK(h, hipFuncSetAttribute((const void *)(kb_scatter2_kernel<KW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a2));
+            HIPCHK(h, hipFuncSetAttribute((const void *)kb_finesort2_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b2));
+            h->sk_attrs_set[4 + KW] = true;
+        }
+        const bool sliced = plan.key_parts > 1;
+        const KbPool kp{s.pool, s.chunk_bin, s.chunk_pos, s.chunk_fill, s.bin_nchunks, s.pool_ctr, s.max_chunks, plan.c1, plan.key_parts, plan.key_part};
+        if (sliced) hipLaunchKernelGGL((kb_scatter2_kernel<KW, true>), dim3(grid_a), dim3(KB_THREADS), lds_a2, h->stream, d_packed, d_invalid, n_tiles, h->k, kp, slabs_per_wg, h->ctl);
+        else hipLaunchKernelGGL((kb_scatter2_kernel<KW, false>), dim3(grid_a), dim3(KB_THREADS), lds_a2, h->stream, d_packed, d_invalid, n_tiles, h->k, kp, slabs_per_wg, h->ctl);
+        stamp();                                               // end of the scatter
+        hipLaunchKernelGGL(kb_poolscan_kernel, dim3(1), dim3(KB_THREADS), 0, h->stream, plan, s, (uint32_t)CHUNK);
+        hipLaunchKernelGGL(kb_chunklist_kernel, dim3((unsigned)((max_chunks + 255) / 256)), dim3(256), 0, h->stream, s);
+        stamp();                                               // end of the chunk lists
+        hipLaunchKernelGGL(kb_finesort2_kernel<KW>, dim3((unsigned)max_groups), dim3(KB_THREADS), lds_b2, h->stream, plan, s);
+        stamp();                                               // end of the fine sort
+    } else {
 
     // persistent A0/A1 workgroups: each owns slabs_per_wg consecutive slabs
     const uint64_t n_slabs = (n_tiles + (KB_THREADS / TPT) - 1) / (KB_THREADS / TPT);
     const uint32_t n_wg = (uint32_t)std::min<uint64_t>(n_slabs, 4096);
     const uint32_t slabs_per_wg = (uint32_t)((n_slabs + n_wg - 1) / n_wg);
     const unsigned grid_a = (unsigned)((n_slabs + slabs_per_wg - 1) / slabs_per_wg);
-    const int nbins = 1 << plan.c1;
     if ((rc = kb_reserve(h, 4, (size_t)grid_a * nbins * 4))) return rc;
     if ((rc = kb_reserve(h, 5, (size_t)grid_a * nbins * 4))) return rc;
     s.hist_wg = (uint32_t *)h->kb_buf[4]; s.wg_base = (uint32_t *)h->kb_buf[5];
@@ -740,10 +799,8 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     const uint64_t n_entries_max = n_tiles * KDF_TILE;
     const uint64_t n_chunks_max = n_entries_max / CHUNK + (uint64_t)nbins + 1;
 
-    const uint64_t nb_table = 1ull << (plan.c1 + plan.c2 + plan.sub_bits);
     if ((rc = kb_reserve(h, 0, n_entries_max * 8 * KW))) return rc;         // wide: 16-byte (lo, hi) entries
     if ((rc = kb_reserve(h, 2, n_chunks_max * (size_t)plan.off_stride * 4))) return rc;
-    const size_t failed_bytes = (size_t)((nb_table + 31) / 32) * 4;
     if ((rc = kb_reserve(h, 3, failed_bytes))) return rc;
     s.ent_lo = (uint64_t *)h->kb_buf[0];
     s.chunk_off = (uint32_t *)h->kb_buf[2]; s.failed = (uint32_t *)h->kb_buf[3];
@@ -754,6 +811,7 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     stamp();                                                   // end of A1
     hipLaunchKernelGGL(kb_finesort_kernel<KW>, dim3((unsigned)n_chunks_max), dim3(KB_THREADS), lds_b, h->stream, plan, s);
     stamp();                                                   // end of B
+    }
     if (filtered && (rc = materialize(h))) return rc;
     // narrow keys: lookahead + wave-queue variant of kernel C (debug flag 8 selects the plain loop, for A/B runs)
     const bool var1 = !(h->opt_debug_flags & 8);
@@ -1355,6 +1413,7 @@ void kdf_destroy(kdf_engine *h) {
     for (int i = 0; i < 4; ++i) if (h->stage[i]) (void)hipFree(h->stage[i]);
     for (int i = 0; i < 6; ++i) if (h->kb_buf[i]) (void)hipFree(h->kb_buf[i]);
     for (int i = 0; i < 16; ++i) if (h->sk_buf[i]) (void)hipFree(h->sk_buf[i]);
+    for (int i = 0; i < 8; ++i) if (h->kp_buf[i]) (void)hipFree(h->kp_buf[i]);
     if (h->sieve) (void)hipFree(h->sieve);
     if (h->sk_assign) (void)hipFree(h->sk_assign);
     if (h->sk_weights) (void)hipFree(h->sk_weights);
@@ -1907,6 +1966,7 @@ int kdf_set_option(kdf_engine *h, const char *name, int64_t value) {
     else if (n == "sk_balance") h->opt_sk_balance = (int)value;
     else if (n == "sk_auto") h->opt_sk_auto = (int)value;
     else if (n == "sieve_bits") h->opt_sieve_bits = (int)value;
+    else if (n == "binned_pool") h->opt_binned_pool = (int)value;
     else if (n == "debug_flags") h->opt_debug_flags = (uint32_t)value;
     else return fail(h, KDF_ERR_INVALID, "kdf_set_option: unknown option %s", name);
     return KDF_OK;
@@ -1922,6 +1982,7 @@ int kdf_get_stat(kdf_engine *h, const char *name, int64_t *value) {
     else if (n == "sk_spills") *value = (int64_t)h->stat_sk_spills;
     else if (n == "sk_failed_buckets") *value = (int64_t)h->stat_sk_failed;
     else if (n == "sk_fallbacks") *value = (int64_t)h->stat_sk_fallbacks;
+    else if (n == "binned_pool") *value = h->opt_binned_pool;
     else if (n == "layout") *value = h->t.sk ? (h->t.sk_assign ? 2 : 1) : 0;
     else if (n == "last_count_path") *value = h->last_path;
     else if (n == "ovf_log2cap") *value = h->t.ovf_lo ? (int64_t)h->t.ovf_log2cap : 0;

@@ -121,7 +121,10 @@ class KmerEngine:
         return self._PATHS[self.get_stat("last_count_path")]
 
     def profile_stage_names(self):
-        return self._STAGES.get(self.last_count_path(), self._STAGES["binned"])
+        path = self.last_count_path()
+        if path == "binned" and self.get_stat("binned_pool"):
+            return ["kb_scatter2_kernel", "kb_poolscan+kb_chunklist", "kb_finesort2_kernel", "kb_bucket_kernel"]
+        return self._STAGES.get(path, self._STAGES["binned"])
 
     # -- count / filter ----------------------------------------------------
     def count(self, stream: ReadStream):

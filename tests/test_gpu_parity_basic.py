@@ -332,3 +332,21 @@ def test_count_filtered_through_the_sieve(oracle, k):
             e.count_filtered(st1)
             o1 = oracle.OracleTable(k, 1 << 12).load_filter(flo, fhi).count_reads_filtered(parent[:1000])
             np.testing.assert_array_equal(e.query(lo, hi), o1.query(lo, hi))
+
+
+@pytest.mark.parametrize("k", [31, 47])
+def test_binned_pool_variant_matches_oracle(oracle, k):
+    """Option binned_pool = 1: the scatter without a histogram pass (runs go to 4 KB chunks taken from a pool, the
+    fine sort works on groups of chunks).  Not the default (it measured slower), but it must stay exact."""
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    rng = np.random.default_rng(1300 + k)
+    genome = rng.integers(0, 4, 60000).astype(np.uint8)
+    reads = rand_reads(rng, 3000, 0, 300, genome=genome) + ["", "A" * 500, "N" * 70, "ACGT" * 80]
+    t, (lo, hi, cnt) = oracle_sorted(oracle, k, reads)
+    with KmerEngine(k, capacity_hint=1 << 13) as e:
+        e.set_option("force_path", 2); e.set_option("binned_pool", 1)
+        half = len(reads) // 2
+        e.count(ReadStream.from_strings(reads[:half])); e.count(ReadStream.from_strings(reads[half:]))
+        glo, ghi, gcnt = e.export_ge(0)
+        assert e.stats()[2] == oracle.count_windows(reads, k) and e.get_stat("replayed_buckets") > 0
+        np.testing.assert_array_equal(glo, lo); np.testing.assert_array_equal(ghi, hi); np.testing.assert_array_equal(gcnt, cnt)
