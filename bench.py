@@ -64,6 +64,8 @@ def parse_args(argv=None):
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--genome", type=int, default=100_000_000)
+    ap.add_argument("--path", choices=["auto", "direct", "binned", "superkmer"], default="auto",
+                    help="count pipeline (auto: the engine's choice; the others force it, for profiles and A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=10_000_000)
     ap.add_argument("--rehearse-one-gpu", action="store_true",
@@ -185,6 +187,7 @@ def run_count(args, world, rank, local_rank):
     local_hint = per_batch if len(my_batches) <= 1 else int(per_batch * (0.4 + 0.62 * len(my_batches)))
     eng = KmerEngine(k, capacity_hint=local_hint, device=local_rank)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_option("force_path", {"auto": 0, "direct": 1, "binned": 2, "superkmer": 3}[args.path])
     merger = None
     if world > 1:
         from kmer_denovo_filter_amd.distributed import EngineOps, OwnerPartitionedCount

@@ -88,7 +88,11 @@ int kdf_stats(kdf_engine *h, uint64_t *capacity, uint64_t *distinct, uint64_t *w
  *            a sample whose distinct k-mers exceed one table is counted slice by slice over
  *            the same stream; insert mode only; 0/1 = everything); "binned_max_positions" (positions per
  *            binned pass, <= 2^31: longer streams take several passes); "binned_filtered_min_log2cap"
- *   stats    "binned_passes", "replayed_buckets", "log2cap", "bucket_bits", "layout" (1 = minimizer-bucketed),
+ *            "sk_auto" (1: big batches of narrow keys from k = sk_min_k on take the super-k-mer pipeline by
+ *            themselves), "sk_balance", "binned_pool", "sieve_bits" (bits per filter key; 0 = by size);
+ *            force_path 4 = count --if through the sieve only
+ *   stats    "binned_passes", "replayed_buckets", "log2cap", "bucket_bits", "layout" (0 hash, 1 minimizer-bucketed,
+ *            2 with the balanced assignment table), "binned_pool",
  *            "last_count_path" (0 direct / 1 binned / 2 super-k-mer), "sk_passes", "sk_spills",
  *            "sk_failed_buckets", "sk_fallbacks", "ovf_log2cap" */
 int kdf_set_option(kdf_engine *h, const char *name, int64_t value);

@@ -37,11 +37,19 @@ fetch, nf = per_kernel("fetch", "FETCH_SIZE")
 write, nw = per_kernel("write", "WRITE_SIZE")
 bench = json.load(open(os.path.join(out, "fetch", "bench.json")))
 cfg = bench["config"]
-n_entries = cfg["windows_per_gpu"]
-names = ("kb_hist1_kernel<1", "kb_scatter1_kernel<1", "kb_finesort_kernel<1>", "kb_bucket_kernel<1, 0")   # prefixes of the pass kernels
+n_entries = cfg.get("windows_rank0", cfg.get("windows_per_gpu"))
+pipeline = cfg.get("count_path", "binned")
+wide = cfg["k"] > 32
+# prefixes of the kernels of one count pass, per pipeline
+names = {
+    "binned": ("kb_hist1_kernel<", "kb_colscan_kernel", "kb_scan1_kernel", "kb_scatter1_kernel<", "kb_scatter2_kernel<", "kb_poolscan_kernel",
+               "kb_chunklist_kernel", "kb_finesort_kernel<", "kb_finesort2_kernel<", "kb_bucket_kernel<"),
+    "superkmer": ("sk_extract_kernel<", "sk_binscan_kernel", "sk_chunklist_kernel", "sk_finesort_kernel", "sk_bucket_kernel<",
+                  "sk_spill_insert_kernel", "sk_weight_records_kernel", "sk_assign_kernel"),
+}.get(pipeline, ("kdf_stream_kernel<",))
 rows, total = [], 0.0
 for k in sorted(set(fetch) | set(write)):
-    if not (k.startswith("kb_") or k.startswith("kdf_")):
+    if not (k.startswith("kb_") or k.startswith("kdf_") or k.startswith("sk_")):
         continue
     rd = fetch.get(k, 0.0) * 1024 * 2          # KiB -> B, gfx950 half-count correction
     wr = write.get(k, 0.0) * 1024
@@ -49,21 +57,24 @@ for k in sorted(set(fetch) | set(write)):
     if k.startswith(names):
         total += rd + wr
 summary = {
-    "tag": tag, "reads_per_gpu": cfg["reads_per_gpu"], "k": cfg["k"], "read_len": cfg["read_len"],
-    "windows": n_entries, "distinct": cfg["distinct_per_gpu"], "table_slots": cfg["table_slots"],
+    "tag": tag, "reads_per_gpu": cfg.get("reads_per_batch", cfg.get("reads_per_gpu")), "k": cfg["k"], "read_len": cfg["read_len"],
+    "pipeline": pipeline,
+    "windows": n_entries, "distinct": cfg.get("distinct_rank0_local", cfg.get("distinct_per_gpu")), "table_slots": cfg["table_slots"],
     "hbm_bytes_per_pass": total,
     "hbm_bytes_per_window": total / n_entries,
     "kernels": rows,
     "calibration": {
-        "kernel": "kb_finesort_kernel<1>", "known_read_bytes": n_entries * 8, "known_write_bytes": n_entries * 8,
-        "note": "known = 8 B per entry each way (plus < 1 % offset tables)",
+        "kernel": "kb_finesort_kernel<%d>" % (2 if wide else 1), "known_read_bytes": n_entries * (16 if wide else 8),
+        "known_write_bytes": n_entries * (16 if wide else 8),
+        "note": "binned pipeline: known = one entry each way (plus < 1 % offset tables)",
     },
     "corrections": "FETCH_SIZE KiB x 1024 x 2 (gfx950 half count), WRITE_SIZE KiB x 1024",
 }
 os.makedirs("profiles", exist_ok=True)
 json.dump(summary, open(f"profiles/traffic_{tag}.json", "w"), indent=1)
-json.dump(summary, open("profiles/traffic_latest.json", "w"), indent=1)
+if len(sys.argv) > 3 and sys.argv[3] == "latest":          # the default bench workload: what bench.py reports as roofline.traffic
+    json.dump(summary, open("profiles/traffic_latest.json", "w"), indent=1)
 for r in rows:
     print(f"{r['kernel'][:36]:38s} x{r['dispatches']:<3d} read {r['read_bytes']/1e9:8.3f} GB  write {r['write_bytes']/1e9:8.3f} GB")
 print("known finesort: read %.3f GB write %.3f GB" % (n_entries * 8 / 1e9, n_entries * 8 / 1e9))
-print("pass total %.2f GB = %.1f B/window (algorithmic 16.3125)" % (total / 1e9, total / n_entries))
+print("pass total %.2f GB = %.1f B/window (%s pipeline, k=%d)" % (total / 1e9, total / n_entries, pipeline, cfg["k"]))
