@@ -742,17 +742,28 @@ __device__ __forceinline__ void kb_lds_sat_add(uint32_t *p, uint32_t add) {
 template <int MODE>
 __device__ __forceinline__ void kb_probe_narrow(uint64_t *tlo, uint32_t *tcnt, uint32_t bmask, uint64_t klo, uint32_t sl,
                                                 uint32_t &claimed, bool &failed) {
-    for (uint32_t n = 0;; ++n) {
-        if (n > bmask) { failed = true; break; }
-        uint64_t cur = tlo[sl];
-        if (cur == KDF_EMPTY && MODE == KB_MODE_INSERT) {
-            cur = atomicCAS((unsigned long long *)&tlo[sl], KDF_EMPTY, klo);
-            if (cur == KDF_EMPTY) { claimed++; cur = klo; }
+    // FOUR slots per iteration, their reads in flight together: a wave runs as many iterations as its longest probe, and
+    // every iteration costs scalar exec-mask bookkeeping on the CU's one scalar unit (round 2: the one-slot loop was 40 %
+    // of the super-k-mer bucket kernel's scalar instructions)
+    for (uint32_t n = 0; n <= bmask;) {
+        uint64_t c[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[i] = tlo[(sl + i) & bmask];
+        uint32_t f = 4; bool isk = false;
+#pragma unroll
+        for (int i = 3; i >= 0; --i) { const bool k_ = c[i] == klo, e_ = c[i] == KDF_EMPTY; if (k_ || e_) { f = (uint32_t)i; isk = k_; } }
+        if (f == 4) { sl = (sl + 4) & bmask; n += 4; continue; }
+        const uint32_t at = (sl + f) & bmask;
+        if (!isk) {
+            if (MODE != KB_MODE_INSERT) return;                  // FILTERED: absent
+            const uint64_t old = atomicCAS((unsigned long long *)&tlo[at], KDF_EMPTY, klo);
+            if (old == KDF_EMPTY) { claimed++; isk = true; }
+            else if (old == klo) isk = true;
         }
-        if (cur == klo) { atomicAdd(&tcnt[sl], 1u); break; }
-        if (cur == KDF_EMPTY) break;                         // FILTERED: absent
-        sl = (sl + 1) & bmask;
+        if (isk) { atomicAdd(&tcnt[at], 1u); return; }
+        sl = (at + 1) & bmask; n += f + 1;
     }
+    failed = true;
 }
 
 // wide keys, one ATTEMPT from slot `sl`: 0 done, 1 bucket full, 2 blocked by a slot another lane is publishing.

@@ -503,22 +503,33 @@ __host__ __device__ constexpr size_t sk_bucket_lds(uint32_t bucket_bits) {
            + (size_t)(2 * SK_C_RUNS + 2 + 40 + 8) * 4 + (size_t)SK_C_IC * 2 + (size_t)(SK_C_THREADS / 64) * SK_C_WQ * 14 + (size_t)SK_C_RC * 2 + 16;
 }
 
-// one key into the LDS slice, starting from a slot value read earlier (`cur` may be stale: a slot read as EMPTY may
-// have been taken since -- the CAS tells -- and a slot read as taken stays taken).  false: the key's neighbourhood
-// of KDF_SK_MAXPROBE slots holds neither the key nor room.
+// One key into the LDS slice from slot `sl` on, `n` slots of its probe sequence already seen.  FOUR slots per
+// iteration (their reads in flight together): the loop's exec-mask bookkeeping is scalar work, the scalar unit issues
+// one instruction per cycle for the whole CU, and a wave runs as many iterations as its longest probe -- the one-slot
+// loop made the bucket kernels scalar-issue bound.  false: the key's neighbourhood of `lim` slots holds neither the
+// key nor room.  (A slot read as EMPTY may have been taken since: the CAS tells; a taken slot stays taken.)
 __device__ __forceinline__ bool sk_slice_add(uint64_t *tlo, uint32_t *tcnt, uint32_t bmask, uint32_t lim, uint64_t key, uint32_t mult,
-                                             uint32_t sl, uint64_t cur, uint32_t &claimed, uint32_t n = 0) {
-    if (n >= lim) return false;
-    for (;;) {
-        if (cur == KDF_EMPTY) {
-            cur = atomicCAS((unsigned long long *)&tlo[sl], KDF_EMPTY, key);
-            if (cur == KDF_EMPTY) { ++claimed; cur = key; }
+                                             uint32_t sl, uint64_t /*cur*/, uint32_t &claimed, uint32_t n = 0) {
+    while (n < lim) {
+        uint64_t c[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[i] = tlo[(sl + i) & bmask];
+        // first of the four that holds the key or is empty (4 = none)
+        uint32_t f = 4; bool isk = false;
+#pragma unroll
+        for (int i = 3; i >= 0; --i) { const bool k_ = c[i] == key, e_ = c[i] == KDF_EMPTY; if (k_ || e_) { f = (uint32_t)i; isk = k_; } }
+        if (f < 4 && n + f >= lim) return false;
+        if (f == 4) { sl = (sl + 4) & bmask; n += 4; continue; }
+        const uint32_t at = (sl + f) & bmask;
+        if (!isk) {
+            const uint64_t old = atomicCAS((unsigned long long *)&tlo[at], KDF_EMPTY, key);
+            if (old == KDF_EMPTY) { ++claimed; isk = true; }
+            else if (old == key) isk = true;
         }
-        if (cur == key) { atomicAdd(&tcnt[sl], mult); return true; }
-        if (++n >= lim) return false;
-        sl = (sl + 1) & bmask;
-        cur = tlo[sl];
+        if (isk) { atomicAdd(&tcnt[at], mult); return true; }
+        sl = (at + 1) & bmask; n += f + 1;                      // another key took the slot: go on behind it
     }
+    return false;
 }
 
 template <int MODE>

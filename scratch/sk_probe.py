@@ -10,7 +10,7 @@ flags = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 ds = synth_stream(reads, 150, 100_000_000, seed=20260417, device="cuda", genome_seed=20260417)
 torch.cuda.synchronize()
 e = KmerEngine(31, capacity_hint=hint)
-e.set_option("debug_flags", flags)
+e.set_option("debug_flags", flags); e.set_option("force_path", 3)
 for it in range(3):
     e.clear()
     e.profile(True)
