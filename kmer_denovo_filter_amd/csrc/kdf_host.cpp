@@ -820,6 +820,17 @@ int kdf_bam_open(const char *path, uint32_t flag_off, int collapse, int threads,
     r->flag_off = flag_off; r->collapse = collapse != 0;
     r->fp = fopen(path, "rb");
     if (!r->fp) { rfail(nullptr, KDF_ERR_IO, "cannot open %s", path); delete r; return KDF_ERR_IO; }
+    {   // CRAM by its magic bytes, whatever the file is called: it needs htslib + the reference, which this
+        // library does not link (the reference passes --reference to samtools for it, jellyfish_wrappers.py:159-165)
+        char magic[4] = {0, 0, 0, 0};
+        const size_t got = fread(magic, 1, 4, r->fp);
+        if (got == 4 && memcmp(magic, "CRAM", 4) == 0) {
+            rfail(nullptr, KDF_ERR_IO, "%s is a CRAM file: CRAM input needs htslib, which the MI355X engine does not link; "
+                                       "convert to BAM (samtools view -b) first", path);
+            fclose(r->fp); r->fp = nullptr; delete r; return KDF_ERR_IO;
+        }
+        rewind(r->fp);
+    }
     static const size_t kBuf = 1 << 20;
     setvbuf(r->fp, nullptr, _IOFBF, kBuf);
     r->threads = std::min(threads, 64);

@@ -194,3 +194,16 @@ def test_parallel_parsing_synthetic_runs(tmp_path):
         assert sa and all(x.startswith("chr1,") and x.endswith(",20M30S,60,1;") for x in sa)
         assert any(m[7] is None for m in ref_aux[1]) and any(m[7] is not None for m in ref_aux[1])
         assert _drain(path, flag_off=flag_off, collapse=collapse, threads=5, want_aux=True, max_bases=5000, max_reads=64) == ref_aux
+
+
+def test_cram_is_recognised_by_its_magic_bytes(tmp_path):
+    """A CRAM file under any name is refused with the CRAM message (the check used to look at the
+    file name only, so a CRAM called x.bam failed later as 'not a BAM file')."""
+    from kmer_denovo_filter_amd._native import KdfError
+    from kmer_denovo_filter_amd.reads import bam_reader
+    p = tmp_path / "sample.bam"
+    p.write_bytes(b"CRAM\x03\x00" + b"\0" * 64)
+    with pytest.raises(KdfError) as ei:
+        with bam_reader(str(p)) as rd:
+            next(iter(rd))
+    assert "CRAM" in str(ei.value) and "samtools view -b" in str(ei.value)
