@@ -362,89 +362,6 @@ __global__ __launch_bounds__(KB_THREADS) void kdf_sieve_count_kernel(
     if (lane == 0 && n) atomicAdd(&ctl->windows[((blockIdx.x * 16 + (threadIdx.x >> 6)) % KDF_SHARDS) * 16], (unsigned long long)n);
 }
 
-// ---------------------------------------------------------------------------
-// Sieve, second form (narrow keys, 16 <= k <= 32): ONE sieve word per MINIMIZER RUN instead of per window.  The word
-// is chosen by the window's minimizer (kdf_sk_order of its smallest canonical 12-mer, spread), the two bits inside it
-// by the k-mer's hash.  Consecutive windows share their minimizer for ~9.5 windows, so a thread of 16 windows loads ~2.7
-// words instead of 16 -- the per-window form is bound by one L2 request per window -- and a window whose minimizer no
-// filter key has finds an all-zero word.  The minimizers come from the super-k-mer pipeline's window code (kdf_sk.h).
-template <int K>
-__global__ __launch_bounds__(256) void kdf_sieve2_build_kernel(const uint64_t *__restrict__ klo, uint64_t n, uint64_t *__restrict__ words, uint32_t log2words) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t key = klo[i], hsh = kdf_hash(key, 0);
-    const uint32_t wi = kdf_sk_spread(kdf_sk_min_of_key(key, K)) >> (24 - log2words);
-    atomicOr((unsigned long long *)&words[wi], (1ull << (hsh & 63)) | (1ull << ((hsh >> 6) & 63)));
-}
-
-template <int K>
-__global__ __launch_bounds__(KB_THREADS) void kdf_sieve2_count_kernel(
-    const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid, uint64_t n_tiles,
-    KdfTable t, KdfCtl *ctl, const uint64_t *__restrict__ words, uint32_t log2words, uint32_t slabs_per_wg)
-{
-    constexpr int WPT = SK_WPT;                               // 16 windows per thread: a slab = 16 K positions = 256 tiles
-    constexpr uint32_t TILES_PER_SLAB = KB_THREADS * WPT / 64;
-    __shared__ uint64_t qlo[(KB_THREADS / 64) * KDF_SV_WQ];
-    uint64_t *wqlo = qlo + (threadIdx.x >> 6) * KDF_SV_WQ;
-    const int lane = threadIdx.x & 63;
-    uint32_t wq_n = 0, nwin = 0, claimed = 0;
-    bool full = false;
-    auto drain = [&](uint32_t from, uint32_t cnt) {
-        const bool todo = (uint32_t)lane < cnt;
-        const uint64_t klo = todo ? wqlo[from + lane] : 0;
-        const uint64_t slot = kdf_home(t, kdf_hash(klo, 0));
-        if (todo && !kdf_add_narrow<false>(t, klo, 1u, slot, t.lo[slot], claimed)) full = true;
-    };
-    const uint64_t n_pos = n_tiles * KDF_TILE;
-    const uint64_t slab0 = (uint64_t)blockIdx.x * slabs_per_wg;
-    for (uint32_t sl = 0; sl < slabs_per_wg; ++sl) {
-        const uint64_t P = ((slab0 + sl) * KB_THREADS + threadIdx.x) * WPT;
-        if ((slab0 + sl) * TILES_PER_SLAB >= n_tiles) break;
-        uint32_t mv[WPT + 1], v17 = 0;
-        if (P < n_pos) sk_windows<K>(packed, invalid, 0, 0, P, mv, v17);
-        else {
-#pragma unroll
-            for (int i = 0; i <= WPT; ++i) mv[i] = 0;
-        }
-        const uint32_t valid = (v17 >> 1) & 0xFFFFu;
-        nwin += __popc(valid);
-        if (__ballot(valid != 0) == 0) continue;              // (wave-uniform)
-        // the sieve word of every minimizer run that starts in this thread's windows (window 0 always starts one here)
-        uint64_t w[WPT];
-#pragma unroll
-        for (int u = 0; u < WPT; ++u) {
-            // a run starts at window 0, after an invalid window, and where the minimizer changes
-            const bool chg = u == 0 || !((valid >> (u - 1)) & 1) || ((mv[u + 1] ^ mv[u]) >> 8) != 0;
-            w[u] = (chg && ((valid >> u) & 1)) ? words[kdf_sk_spread(mv[u + 1] >> 8) >> (24 - log2words)] : 0ull;
-        }
-        KbWindows<1> win;
-        win.load(packed, invalid, P >> 6, n_tiles, (int)((P & 63) / WPT), K);
-        uint64_t cur = 0;
-#pragma unroll
-        for (int u = 0; u < WPT; ++u) {
-            const bool chg = u == 0 || !((valid >> (u - 1)) & 1) || ((mv[u + 1] ^ mv[u]) >> 8) != 0;
-            if (chg) cur = w[u];
-            if (!((valid >> u) & 1)) continue;
-            uint64_t lo, hi; win.key(u, lo, hi);
-            const uint64_t hsh = kdf_hash(lo, 0);
-            const bool ok = ((cur >> (hsh & 63)) & (cur >> ((hsh >> 6) & 63)) & 1ull) != 0;
-            const unsigned long long mk = __ballot(ok);
-            if (mk) {
-                const uint32_t at = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-                if (ok) wqlo[at] = lo;
-                wq_n += (uint32_t)__popcll(mk);
-                if (wq_n >= 64) { wq_n -= 64; drain(wq_n, 64); }
-            }
-        }
-    }
-    if (wq_n) drain(0, wq_n);
-    if (full) atomicOr(&ctl->error, 1u);
-    uint32_t n = nwin;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
-    if (lane == 0 && n) atomicAdd(&ctl->windows[((blockIdx.x * 16 + (threadIdx.x >> 6)) % KDF_SHARDS) * 16], (unsigned long long)n);
-}
-
 __global__ void kdf_ctl_reduce_kernel(KdfCtl *ctl, unsigned long long *out3) {
     // out3 = {distinct, windows, error}; single wave
     unsigned long long d = ctl->distinct[threadIdx.x * 16], w = ctl->windows[threadIdx.x * 16], y = ctl->tally[threadIdx.x * 16];
@@ -510,10 +427,6 @@ struct kdf_engine {
     uint64_t *sieve = nullptr;                       // blocked Bloom filter over the filter keys (count --if)
     uint64_t sieve_words = 0, sieve_alloc = 0;
     bool sieve_valid = false;
-    uint64_t *sieve2 = nullptr;                      // second form: one word per minimizer run (narrow keys, k >= 16)
-    uint64_t sieve2_alloc = 0; uint32_t sieve2_log2 = 0;
-    bool sieve2_valid = false;
-    int opt_sieve_form = 0, opt_sieve2_log2 = 0;     // 0 auto / 1 per-window form / 2 per-run form; words of the per-run sieve (0 auto)
     uint32_t opt_debug_flags = 0;                    // experiments only (KbPlan::dbg)
     uint64_t stat_binned_passes = 0, stat_replayed_buckets = 0;
     uint64_t stat_dbg[6] = {0, 0, 0, 0, 0, 0};        // diagnostic stamps of the last binned pass
@@ -1410,25 +1323,6 @@ static int count_filtered_dev(kdf_engine *h, const uint64_t *d_packed, const uin
     const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
     if (n_tiles == 0) return KDF_OK;
     { int rc0 = materialize(h); if (rc0) return rc0; }
-    if (h->sieve2_valid && !h->t.sk && h->opt_sieve_form != 1 && (h->opt_force_path == 0 || h->opt_force_path == 4)) {
-        const uint64_t tiles_per_slab = KB_THREADS * SK_WPT / 64;
-        const uint64_t n_slabs = (n_tiles + tiles_per_slab - 1) / tiles_per_slab;
-        const uint32_t n_wg = (uint32_t)std::min<uint64_t>(n_slabs, (uint64_t)h->n_cu * 8);
-        const uint32_t spw = (uint32_t)((n_slabs + n_wg - 1) / n_wg);
-        const unsigned grid = (unsigned)((n_slabs + spw - 1) / spw);
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (h->prof) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, h->stream); }
-        switch (h->k) {
-#define SV2_CASE(KK) case KK: hipLaunchKernelGGL(kdf_sieve2_count_kernel<KK>, dim3(grid), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->t, h->ctl, (const uint64_t *)h->sieve2, h->sieve2_log2, spw); break;
-            SV2_CASE(16) SV2_CASE(17) SV2_CASE(18) SV2_CASE(19) SV2_CASE(20) SV2_CASE(21) SV2_CASE(22) SV2_CASE(23) SV2_CASE(24)
-            SV2_CASE(25) SV2_CASE(26) SV2_CASE(27) SV2_CASE(28) SV2_CASE(29) SV2_CASE(30) SV2_CASE(31) SV2_CASE(32)
-#undef SV2_CASE
-        }
-        if (h->prof) { (void)hipEventRecord(e1, h->stream); h->prof_ev.emplace_back(e0, e1); h->prof_tiles.push_back(n_tiles); }
-        HIPCHK(h, hipGetLastError());
-        h->last_path = 4;
-        return KDF_OK;
-    }
     if (h->sieve_valid && !h->t.sk && (h->opt_force_path == 0 || h->opt_force_path == 4)) {
         // persistent workgroups over slabs of 1024 x WPT positions
         const int WPT = h->kw == 1 ? KbCfg<1>::WPT : KbCfg<2>::WPT;
@@ -1527,7 +1421,6 @@ void kdf_destroy(kdf_engine *h) {
     for (int i = 0; i < 16; ++i) if (h->sk_buf[i]) (void)hipFree(h->sk_buf[i]);
     for (int i = 0; i < 8; ++i) if (h->kp_buf[i]) (void)hipFree(h->kp_buf[i]);
     if (h->sieve) (void)hipFree(h->sieve);
-    if (h->sieve2) (void)hipFree(h->sieve2);
     if (h->sk_assign) (void)hipFree(h->sk_assign);
     if (h->sk_weights) (void)hipFree(h->sk_weights);
     if (h->sk_ctrs) (void)hipFree(h->sk_ctrs);
@@ -1561,7 +1454,7 @@ int kdf_clear(kdf_engine *h) {
     int rc = ctl_reset(h, false);
     if (rc) return rc;
     h->distinct = 0; h->windows = 0; h->filter_mode = false;
-    h->lazy_empty = true; h->sieve_valid = false; h->sieve2_valid = false;
+    h->lazy_empty = true; h->sieve_valid = false;
     sk_leave(h);                  // layouts are chosen per table generation: the next count decides again
     return KDF_OK;
 }
@@ -1649,7 +1542,6 @@ static int load_filter_core(kdf_engine *h, const uint64_t *d_lo, const uint64_t 
         const uint64_t words = std::max<uint64_t>(1024, 1ull << log2ceil((bits + 63) / 64));
         if (h->sieve_alloc < words) {
             if (h->sieve) (void)hipFree(h->sieve);
-    if (h->sieve2) (void)hipFree(h->sieve2);
             h->sieve = nullptr; h->sieve_alloc = 0;
             HIPCHK(h, hipMalloc((void **)&h->sieve, words * 8));
             h->sieve_alloc = words;
@@ -1661,28 +1553,6 @@ static int load_filter_core(kdf_engine *h, const uint64_t *d_lo, const uint64_t 
         else hipLaunchKernelGGL(kdf_sieve_build_kernel<2>, dim3(blocks), dim3(256), 0, h->stream, d_lo, d_hi, n, h->sieve, words - 1);
         HIPCHK(h, hipGetLastError());
         h->sieve_valid = true;
-    }
-    h->sieve2_valid = false;
-    if (h->kw == 1 && h->k >= SK_MIN_K && h->opt_sieve_form != 1 && n <= (1ull << 26)) {
-        // ~10 filter keys share a minimizer: two words per expected marked minimizer, 2^12 .. 2^22 words
-        const uint32_t lg = h->opt_sieve2_log2 ? (uint32_t)h->opt_sieve2_log2 : std::min<uint32_t>(22, std::max<uint32_t>(12, log2ceil(std::max<uint64_t>(n, 2) / 2)));
-        const uint64_t words = 1ull << lg;
-        if (h->sieve2_alloc < words) {
-            if (h->sieve2) (void)hipFree(h->sieve2);
-            h->sieve2 = nullptr; h->sieve2_alloc = 0;
-            HIPCHK(h, hipMalloc((void **)&h->sieve2, words * 8));
-            h->sieve2_alloc = words;
-        }
-        h->sieve2_log2 = lg;
-        HIPCHK(h, hipMemsetAsync(h->sieve2, 0, words * 8, h->stream));
-        if (n) switch (h->k) {
-#define SV2_CASE(KK) case KK: hipLaunchKernelGGL(kdf_sieve2_build_kernel<KK>, dim3(blocks), dim3(256), 0, h->stream, d_lo, n, h->sieve2, lg); break;
-            SV2_CASE(16) SV2_CASE(17) SV2_CASE(18) SV2_CASE(19) SV2_CASE(20) SV2_CASE(21) SV2_CASE(22) SV2_CASE(23) SV2_CASE(24)
-            SV2_CASE(25) SV2_CASE(26) SV2_CASE(27) SV2_CASE(28) SV2_CASE(29) SV2_CASE(30) SV2_CASE(31) SV2_CASE(32)
-#undef SV2_CASE
-        }
-        HIPCHK(h, hipGetLastError());
-        h->sieve2_valid = true;
     }
     return KDF_OK;
 }
@@ -1726,7 +1596,7 @@ int kdf_reset_counts(kdf_engine *h) {
 // pairs fit at load <= 0.5 even if all of them are new
 static int add_pairs_dev(kdf_engine *h, const uint64_t *d_lo, const uint64_t *d_hi, const uint32_t *d_cnt, uint64_t n) {
     if (n == 0) return KDF_OK;
-    h->sieve_valid = false; h->sieve2_valid = false; // keys may join the table that the sieves have not seen
+    h->sieve_valid = false;                          // keys may join the table that the sieve has not seen
     int rc = materialize(h);
     if (rc) return rc;
     if ((rc = ctl_sync(h, nullptr))) return rc;
@@ -2104,8 +1974,6 @@ int kdf_set_option(kdf_engine *h, const char *name, int64_t value) {
     else if (n == "sk_balance") h->opt_sk_balance = (int)value;
     else if (n == "sk_auto") h->opt_sk_auto = (int)value;
     else if (n == "sieve_bits") h->opt_sieve_bits = (int)value;
-    else if (n == "sieve_form") h->opt_sieve_form = (int)value;
-    else if (n == "sieve2_log2words") h->opt_sieve2_log2 = (int)value;
     else if (n == "binned_pool") h->opt_binned_pool = (int)value;
     else if (n == "debug_flags") h->opt_debug_flags = (uint32_t)value;
     else return fail(h, KDF_ERR_INVALID, "kdf_set_option: unknown option %s", name);

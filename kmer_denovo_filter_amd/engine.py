@@ -110,7 +110,7 @@ class KmerEngine:
         self._ck(self._lib.kdf_profile_stages(self._h, ms, byref(n)))
         return list(ms), n.value
 
-    _PATHS = ("direct", "binned", "superkmer", "sieve", "sieve-per-run")
+    _PATHS = ("direct", "binned", "superkmer", "sieve")
     _STAGES = {
         "binned": ["kb_hist1_kernel(+scans)", "kb_scatter1_kernel", "kb_finesort_kernel", "kb_bucket_kernel"],
         "superkmer": ["sk_extract_kernel", "sk_binscan+sk_chunklist", "sk_finesort_kernel", "sk_bucket_kernel"],

@@ -98,14 +98,13 @@ def test_config2_parent_filter_chain_full_64mbp():
     assert res["candidates"] > res["non_ref"] > res["after_mother"] > res["after_father"] == res["proband_unique"] > 0
     # 64 000 planted SNVs x up to 31 k-mers each, seen >= 3 times at 30x: the bulk of the non-reference set
     assert 1_500_000 < res["proband_unique"] < 64_000 * 31
-    assert res["stages"]["mother_count_if"]["path"] == "sieve-per-run"
+    assert res["stages"]["mother_count_if"]["path"] == "sieve"
     assert np.all(lo[1:] != lo[:-1])
     dlo, _ = devkeys.from_host(lo, None, False)
     mother = streams["mother"]
     counts = []
-    for path, form in ((4, 2), (4, 1), (2, 0), (1, 0)):      # sieve per minimizer run, sieve per window, binned, direct
+    for path in (4, 2, 1):                                   # sieve, binned, direct
         with KmerEngine(31, capacity_hint=len(lo)) as e:
-            e.set_option("sieve_form", form)
             e.load_filter_dev(dlo.data_ptr(), None, len(lo))
             e.set_option("force_path", path)
             e.count_filtered_dev(mother.packed.data_ptr(), mother.invalid.data_ptr(), mother.n_bases)

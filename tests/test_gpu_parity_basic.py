@@ -307,13 +307,11 @@ def test_count_filtered_through_the_sieve(oracle, k):
     parent = rand_reads(rng, 3000, 0, 260, genome=genome) + ["A" * 300] * 20
     _, (lo, hi, _) = oracle_sorted(oracle, k, child + ["A" * 100])
     st1, st2 = ReadStream.from_strings(parent[:1000]), ReadStream.from_strings(parent[1000:])
-    # narrow keys have two forms of the sieve: a word per window (1) and a word per minimizer run (2, the default)
-    for frac, form in [(f, m) for f in (0.0, 0.01, 0.4, 1.0) for m in ((1, 2) if k <= 32 else (1,))]:
+    for frac in (0.0, 0.01, 0.4, 1.0):
         sel = rng.random(len(lo)) < frac if frac < 1.0 else np.ones(len(lo), bool)
         flo, fhi = lo[sel], hi[sel]
         ot = oracle.OracleTable(k, 1 << 12).load_filter(flo, fhi).count_reads_filtered(parent)
         with KmerEngine(k) as e:
-            e.set_option("sieve_form", form)
             if frac == 0.4:                                   # device-resident filter keys
                 dl = torch.from_numpy(flo.view(np.int64).copy()).cuda()
                 dh = torch.from_numpy(fhi.view(np.int64).copy()).cuda() if k > 32 else None
@@ -322,7 +320,7 @@ def test_count_filtered_through_the_sieve(oracle, k):
                 e.load_filter(flo, fhi)
             e.set_option("force_path", 4)
             e.count_filtered(st1); e.count_filtered(st2)
-            assert e.last_count_path() == ("sieve" if form == 1 else "sieve-per-run")
+            assert e.last_count_path() == "sieve"
             assert e.stats()[2] == oracle.count_windows(parent, k)
             np.testing.assert_array_equal(e.query(lo, hi), ot.query(lo, hi))
             glo, _, gcnt = e.export_ge(0)
