@@ -220,3 +220,51 @@ def test_superkmer_refuses_what_it_cannot_do():
             e.set_option("force_path", 3)
             with pytest.raises(KdfError):
                 e.count(ReadStream.from_strings(["ACGT" * 30]))
+
+
+def _repeat_rich_genome(rng, n_bases=300_000):
+    """A genome the way real ones are skewed (VERDICT r1 weak point 9): an Alu-like 300 bp element copied every
+    ~1.5 kb with 10 % divergence per copy, microsatellites ((CA)n, (GAA)n, poly-A runs) of 40-200 bp, the rest
+    unique sequence.  Many DISTINCT k-mers share the minimizers inside the repeat consensus."""
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    alu = rng.integers(0, 4, 300)
+    out, n = [], 0
+    while n < n_bases:
+        piece = rng.integers(0, 4, int(rng.integers(600, 2400)))
+        out.append(piece); n += len(piece)
+        copy = alu.copy()
+        mut = rng.random(300) < 0.10
+        copy[mut] = rng.integers(0, 4, int(mut.sum()))
+        out.append(copy if rng.random() < 0.5 else (3 - copy)[::-1]); n += 300
+        unit = [np.array([1, 0]), np.array([2, 0, 0]), np.array([0])][int(rng.integers(0, 3))]
+        sat = np.tile(unit, int(rng.integers(40, 200)) // len(unit) + 1)
+        out.append(sat); n += len(sat)
+    return np.concatenate(out).astype(np.uint8)
+
+
+@pytest.mark.parametrize("path", [2, 3])
+def test_repeat_rich_genome_both_count_pipelines(oracle, path):
+    """Skewed input at a size where buckets really fill: 20x reads with errors from a repeat-rich genome, counted by
+    the binned pipeline (hash buckets) and the super-k-mer pipeline (minimizer buckets), in two batches, small table."""
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    k = 31
+    rng = np.random.default_rng(77)
+    genome = _repeat_rich_genome(rng)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    reads = []
+    for _ in range(40_000):
+        s = int(rng.integers(0, len(genome) - 150))
+        r = genome[s:s + 150].copy()
+        err = rng.random(150) < 0.005
+        r[err] = (r[err] + rng.integers(1, 4, int(err.sum()))) & 3
+        if rng.random() < 0.5:
+            r = (3 - r)[::-1]
+        reads.append(acgt[r].tobytes().decode())
+    t, (lo, hi, cnt) = oracle_sorted(oracle, k, reads)
+    with KmerEngine(k, capacity_hint=1 << 16) as e:               # far too small: the table grows (re-deals) under load
+        e.set_option("force_path", path)
+        e.count(ReadStream.from_strings(reads[:25_000]))
+        e.count(ReadStream.from_strings(reads[25_000:]))
+        check_equal(e, oracle, k, reads, lo, hi, cnt)
+        assert int(cnt.max()) > 2000                               # the microsatellite k-mers are heavy hitters
+        np.testing.assert_array_equal(e.query(lo[::13], hi[::13]), cnt[::13])
