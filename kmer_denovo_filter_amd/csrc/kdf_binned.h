@@ -76,6 +76,7 @@ struct KbPlan {
     uint32_t off_stride;    // entries per row of chunk_off = 2^c2 + 1
     uint32_t key_parts, key_part;   // KdfTable::key_parts: windows of other key-space slices are dropped in A0 / A1
     uint32_t dbg;           // experiments only (bucket kernel, plain-loop variant): 1 skip LDS insert, 4 skip write-back
+    uint32_t cells;         // 1: the partition was built without a histogram pass (fixed cells); the windows A1 counted wait in totals[5]
 };
 
 // device scratch shared by the kernels of one pass
@@ -286,10 +287,15 @@ __device__ __forceinline__ void kb_lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int KW, bool SLICED>
+// CELLS: no histogram pass ran.  Every (bin, workgroup) pair owns a CELL of CHUNK entries -- chunk number
+// bin * gridDim.x + workgroup of the entry buffer -- and the workgroup's cursor of the bin starts at the cell's base; the
+// cell's fill goes to hist_wg[chunk] at the end and the valid windows are counted here.  A cell that would overflow
+// (a bin far above the mean inside one workgroup's slabs) raises failed_flag: the later stages then do nothing and the
+// host redoes the pass with the exact layout (A0 first).
+template <int KW, bool SLICED, bool CELLS = false>
 __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
     const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid, uint64_t n_tiles, int k,
-    KbPlan plan, KbScratch s, uint32_t slabs_per_wg)
+    KbPlan plan, KbScratch s, uint32_t slabs_per_wg, KdfCtl *ctl = nullptr)
 {
     constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT, SLAB = KB_THREADS * WPT;
     constexpr uint32_t TILES_PER_SLAB = KB_THREADS / TPT;
@@ -305,11 +311,17 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
     constexpr int DUMMY = 1 << KB_C1_MAX;
     const int nb = 1 << plan.c1;
     if (threadIdx.x == 0) { hist[DUMMY] = 0; offs[DUMMY] = (uint32_t)SLAB; }
+    if (CELLS && threadIdx.x == 0) wsum[31] = 0, wsum[30] = 0;          // valid windows of this workgroup (64-bit, lane 63 adds)
     for (int i = threadIdx.x; i < nb; i += KB_THREADS) {
         hist[i] = 0;
-        const unsigned long long st = s.bin_start[i] + s.wg_base[(uint64_t)blockIdx.x * nb + i];
-        gcur[i] = st;
-        gend[i] = st + s.hist_wg[(uint64_t)blockIdx.x * nb + i];
+        if constexpr (CELLS) {
+            const unsigned long long st = ((unsigned long long)i * gridDim.x + blockIdx.x) * KbCfg<KW>::CHUNK;
+            gcur[i] = st; gend[i] = st + KbCfg<KW>::CHUNK;
+        } else {
+            const unsigned long long st = s.bin_start[i] + s.wg_base[(uint64_t)blockIdx.x * nb + i];
+            gcur[i] = st;
+            gend[i] = st + s.hist_wg[(uint64_t)blockIdx.x * nb + i];
+        }
     }
     __syncthreads();
     const uint64_t slab0 = (uint64_t)blockIdx.x * slabs_per_wg;
@@ -361,6 +373,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
             for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if ((int)threadIdx.x >= o) inc += t; }
             uint32_t run = inc - sum;
             for (int i = 0; i < per; ++i) if (b0 + i < nb) { offs[b0 + i] = run; run += hist[b0 + i]; }
+            if (CELLS && threadIdx.x == 63) atomicAdd((unsigned long long *)&wsum[30], (unsigned long long)inc);   // lane 63: the slab's valid windows
         }
         kb_lds_barrier();                                               // B2: offsets ready
         {
@@ -400,10 +413,31 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
         kb_lds_barrier();                                               // B4: hist is zero, image free (stores still draining)
         win = nxt;
     }
+    if constexpr (CELLS) {
+        for (int i = threadIdx.x; i < nb; i += KB_THREADS) {
+            const unsigned long long chunk = (unsigned long long)i * gridDim.x + blockIdx.x;
+            s.hist_wg[chunk] = (uint32_t)(gcur[i] - chunk * KbCfg<KW>::CHUNK);
+        }
+        if (threadIdx.x == 0) {
+            // not into ctl->windows yet: if a cell overflowed somewhere the pass is redone (kernel C adds totals[5])
+            const unsigned long long w = *(unsigned long long *)&wsum[30];
+            if (w) atomicAdd(&s.totals[5], w);
+        }
+    }
+}
+
+// cells: the arrays kernel C reads, for nbins x n_wg cells of CHUNK entries (chunk j of the bins starts at j * CHUNK)
+__global__ __launch_bounds__(KB_THREADS) void kb_cellscan_kernel(KbPlan plan, KbScratch s, uint32_t chunk_entries, uint32_t n_wg) {
+    const int nb = 1 << plan.c1;
+    for (int i = threadIdx.x; i <= nb; i += KB_THREADS) { s.chunk_first[i] = (unsigned long long)i * n_wg; s.bin_start[i] = (unsigned long long)i * n_wg * chunk_entries; }
+    if (threadIdx.x == 0) {
+        s.totals[0] = 0; s.totals[1] = (unsigned long long)nb * n_wg; s.totals[2] = 0; s.totals[3] = 0; s.totals[5] = 0;
+        for (int i = 9; i < 16; ++i) s.totals[i] = 0;             // (totals[8] holds failed_flag: the host cleared it)
+    }
 }
 
 // B: one workgroup per chunk; in-place sort by fine bin + offset table
-template <int KW>
+template <int KW, bool CELLS = false>
 __global__ __launch_bounds__(KB_THREADS) void kb_finesort_kernel(KbPlan plan, KbScratch s)
 {
     constexpr int CHUNK = KbCfg<KW>::CHUNK, EPT = CHUNK / KB_THREADS;
@@ -417,7 +451,11 @@ __global__ __launch_bounds__(KB_THREADS) void kb_finesort_kernel(KbPlan plan, Kb
     unsigned long long &sh_start = *(unsigned long long *)(wsum + 32);
     uint32_t &sh_len = *(uint32_t *)(wsum + 34);
     const uint64_t chunk = blockIdx.x;
+    if (CELLS && s.failed_flag[0]) return;                  // a cell overflowed: the host redoes the pass, nothing may be used
     if (chunk >= s.totals[1]) return;                       // the grid covers the largest possible number of chunks
+    if (CELLS) {
+        if (threadIdx.x == 0) { sh_start = chunk * (unsigned long long)CHUNK; sh_len = s.hist_wg[chunk]; }
+    } else
     if (threadIdx.x == 0) {
         // locate the coarse bin of this chunk: chunk_first is ascending
         const int nb = 1 << plan.c1;
@@ -478,7 +516,8 @@ __global__ __launch_bounds__(KB_THREADS) void kb_finesort_kernel(KbPlan plan, Kb
             // words, in the same 16 * len bytes -- because kernel C's gathers run faster on two 8-byte
             // streams than on 16-byte entries (measured: 15.5 vs 17.0 ms at k = 63)
             const KbEnt2 v = s2[i];
-            s.ent_lo[2 * start + i] = v.lo; s.ent_lo[2 * start + len + i] = v.hi;
+            // (cells may be partly filled anywhere in a bin: kernel C then finds the hi words at + CHUNK, see kb_finesort2)
+            s.ent_lo[2 * start + i] = v.lo; s.ent_lo[2 * start + (CELLS ? (uint32_t)CHUNK : len) + i] = v.hi;
         } else s.ent_lo[start + i] = slo[i];
     }
 }
@@ -842,6 +881,9 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
     // Workgroups are dealt to the 8 XCDs round robin by blockIdx, and each XCD has its own L2.  Neighbouring buckets
     // (f, f + 1 of one coarse bin) read neighbouring runs of the same chunks -- they share the cache line at every run
     // boundary and the lines of the offset table -- so an XCD takes a contiguous eighth of the buckets, in order.
+    if (s.failed_flag[0]) return;                              // the partition is not usable (a cell overflowed / the stream changed): the host knows
+    if (plan.cells && MODE != KB_MODE_REPLAY && blockIdx.x == 0 && threadIdx.x == 0 && s.totals[5])
+        atomicAdd(&ctl->windows[0], s.totals[5]);              // the valid windows the cell scatter counted
     const uint32_t nbk = gridDim.x;
     const uint64_t bucket = (nbk & 7) ? blockIdx.x : (uint64_t)(blockIdx.x & 7) * (nbk >> 3) + (blockIdx.x >> 3);   // table bucket of `plan`
     const uint64_t pb = bucket >> plan.sub_bits;              // partition bucket holding its entries

@@ -405,6 +405,8 @@ struct kdf_engine {
     uint32_t opt_binned_filtered_min_log2cap = 23;   // count --if goes binned from 2^23 slots (measured crossover)
     int opt_force_path = 0;                          // 0 auto, 1 direct, 2 binned, 3 super-k-mer (kdf_sk.h)
     uint32_t opt_sk_min_k = 20;                      // auto (option sk_auto): narrow keys from this k on take the super-k-mer path
+    int opt_binned_cells = 1;                        // binned path: no histogram pass, fixed (bin, workgroup) cells; falls back to A0 + A1 when a cell overflows
+    bool cells_overflowed = false;                   // sticky: this engine's input is too skewed for fixed cells
     int opt_binned_pool = 0;                         // binned path: 1 = pool scatter without the histogram pass (measured SLOWER: 6.4 ms
                                                      // against A0 + A1 = 5.9 ms, the scatter sits at the 128-VGPR limit), 0 = A0 + A1 + B
     void *kp_buf[8] = {nullptr};                     // pool variant: pool, chunk_bin, chunk_pos, chunk_fill, chunk_list, small, pool_ctr
@@ -676,7 +678,7 @@ static int kb_set_lds_attrs(kdf_engine *h, size_t a1, size_t b, size_t c) {
 
 static int table_rehash(kdf_engine *h, uint32_t new_log2);
 template <int KW>
-static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases, bool filtered);
+static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases, bool filtered, bool force_exact = false);
 
 // the binned path over a stream of any length: passes of at most opt_binned_max_positions
 // positions, each starting on a tile boundary (windows that start in a pass may read on
@@ -697,10 +699,11 @@ static int kb_passes(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_
 
 // one pass of the binned pipeline over a device-resident stream
 template <int KW>
-static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases, bool filtered) {
+static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases, bool filtered, bool force_exact) {
     constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT, CHUNK = KbCfg<KW>::CHUNK, SLAB = KB_THREADS * WPT;
     const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
     if (n_tiles == 0) return KDF_OK;
+    const bool was_lazy = h->lazy_empty;
     KbPlan plan = kb_make_plan(h->t);
     plan.dbg = h->opt_debug_flags;
     plan.key_parts = filtered ? 0 : h->t.key_parts; plan.key_part = h->t.key_part;
@@ -732,7 +735,36 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     const uint64_t nb_table = 1ull << (plan.c1 + plan.c2 + plan.sub_bits);
     const size_t failed_bytes = (size_t)((nb_table + 31) / 32) * 4;
     const int nbins = 1 << plan.c1;
-    if (h->opt_binned_pool) {
+    // cells: wide keys by default (measured at 10 M reads: k = 63 26.2 -> 24.3 ms; k = 31 14.3 -> 14.6 ms, where the
+    // emptier chunks cost B and C more than the histogram pass saves); option value 2 = any key width and batch size
+    const bool cells = h->opt_binned_cells && !h->opt_binned_pool && !force_exact && !h->cells_overflowed &&
+                       (h->opt_binned_cells > 1 || (KW == 2 && n_tiles * KDF_TILE >= (1ull << 26)));
+    plan.cells = cells ? 1u : 0u;
+    if (cells) {
+        // ---- no histogram pass: every (bin, workgroup) owns a cell of CHUNK entries; A1 fills the cells, B sorts each
+        // cell in place, kernel C reads them as the chunks of the bins
+        const uint64_t n_slabs = (n_tiles + (KB_THREADS / TPT) - 1) / (KB_THREADS / TPT);
+        const uint32_t n_wg = (uint32_t)std::min<uint64_t>(n_slabs, (uint64_t)h->n_cu);
+        const uint32_t slabs_per_wg = (uint32_t)((n_slabs + n_wg - 1) / n_wg);
+        const unsigned grid_a = (unsigned)((n_slabs + slabs_per_wg - 1) / slabs_per_wg);
+        const uint64_t n_cells = (uint64_t)grid_a * nbins;
+        if ((rc = kb_reserve(h, 0, n_cells * CHUNK * 8 * KW))) return rc;
+        if ((rc = kb_reserve(h, 2, n_cells * (size_t)plan.off_stride * 4))) return rc;
+        if ((rc = kb_reserve(h, 3, failed_bytes))) return rc;
+        if ((rc = kb_reserve(h, 4, n_cells * 4))) return rc;
+        s.ent_lo = (uint64_t *)h->kb_buf[0];
+        s.chunk_off = (uint32_t *)h->kb_buf[2]; s.failed = (uint32_t *)h->kb_buf[3]; s.hist_wg = (uint32_t *)h->kb_buf[4];
+        HIPCHK(h, hipMemsetAsync(s.failed, 0, failed_bytes, h->stream));
+        HIPCHK(h, hipMemsetAsync(s.failed_flag, 0, 4, h->stream));
+        hipLaunchKernelGGL(kb_cellscan_kernel, dim3(1), dim3(KB_THREADS), 0, h->stream, plan, s, (uint32_t)CHUNK, (uint32_t)grid_a);
+        const bool sliced = plan.key_parts > 1;
+        if (sliced) hipLaunchKernelGGL((kb_scatter1_kernel<KW, true, true>), dim3(grid_a), dim3(KB_THREADS), lds_a1, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg, h->ctl);
+        else hipLaunchKernelGGL((kb_scatter1_kernel<KW, false, true>), dim3(grid_a), dim3(KB_THREADS), lds_a1, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg, h->ctl);
+        stamp();                                               // end of the scatter
+        stamp();                                               // (no second stage)
+        hipLaunchKernelGGL((kb_finesort_kernel<KW, true>), dim3((unsigned)n_cells), dim3(KB_THREADS), lds_b, h->stream, plan, s);
+        stamp();                                               // end of the fine sort
+    } else if (h->opt_binned_pool) {
         // ---- one pass over the stream: scatter into pool chunks, chunk lists, fine sort of chunk groups
         constexpr int PCH = KB_PCH(KW);
         const uint64_t n_slabs = (n_tiles + (KB_THREADS / TPT) - 1) / (KB_THREADS / TPT);
@@ -844,6 +876,14 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     h->stat_binned_passes++;
     h->lazy_empty = false;
     for (int i = 0; i < 6; ++i) h->stat_dbg[i] = h->kb_totals_host[9 + i];
+    if (((unsigned int *)(h->kb_totals_host + 8))[0] && cells) {
+        // a cell overflowed: B and C did nothing (they saw the flag).  The windows A1 counted are taken back and the
+        // pass is redone with the exact layout; this engine stays on it (its input is skewed).
+        h->cells_overflowed = true;
+        h->stat_binned_passes--;
+        h->lazy_empty = was_lazy;
+        return kb_pass<KW>(h, d_packed, d_invalid, n_bases, filtered, true);
+    }
     if (((unsigned int *)(h->kb_totals_host + 8))[0])
         return fail(h, KDF_ERR_STATE, "binned count: the read stream changed while it was being counted "
                                       "(is another stream still writing it? synchronise before the call)");
@@ -854,7 +894,7 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     // that even if every entry of the failed buckets were new the load stays
     // <= 0.5, then replay exactly those buckets through the global-atomic path.
     h->stat_replayed_buckets += n_failed;
-    const uint64_t n_entries = h->kb_totals_host[0];
+    const uint64_t n_entries = cells ? h->kb_totals_host[5] : h->kb_totals_host[0];     // (cells: the windows the scatter counted)
     const uint64_t worst = h->distinct + std::min<uint64_t>(n_entries, n_failed * ((n_entries / std::max<uint64_t>(nb_table, 1)) * 4 + 4096));
     uint32_t want = std::max<uint32_t>(h->t.log2cap + 1, cap_log2_for(worst));
     if ((rc = table_rehash(h, want))) return rc;
@@ -1975,6 +2015,7 @@ int kdf_set_option(kdf_engine *h, const char *name, int64_t value) {
     else if (n == "sk_auto") h->opt_sk_auto = (int)value;
     else if (n == "sieve_bits") h->opt_sieve_bits = (int)value;
     else if (n == "binned_pool") h->opt_binned_pool = (int)value;
+    else if (n == "binned_cells") { h->opt_binned_cells = (int)value; h->cells_overflowed = false; }
     else if (n == "debug_flags") h->opt_debug_flags = (uint32_t)value;
     else return fail(h, KDF_ERR_INVALID, "kdf_set_option: unknown option %s", name);
     return KDF_OK;
@@ -1991,6 +2032,7 @@ int kdf_get_stat(kdf_engine *h, const char *name, int64_t *value) {
     else if (n == "sk_failed_buckets") *value = (int64_t)h->stat_sk_failed;
     else if (n == "sk_fallbacks") *value = (int64_t)h->stat_sk_fallbacks;
     else if (n == "binned_pool") *value = h->opt_binned_pool;
+    else if (n == "binned_cells") *value = (h->opt_binned_cells && !h->cells_overflowed) ? h->opt_binned_cells : 0;
     else if (n == "layout") *value = h->t.sk ? (h->t.sk_assign ? 2 : 1) : 0;
     else if (n == "last_count_path") *value = h->last_path;
     else if (n == "ovf_log2cap") *value = h->t.ovf_lo ? (int64_t)h->t.ovf_log2cap : 0;

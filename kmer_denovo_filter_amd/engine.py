@@ -122,6 +122,8 @@ class KmerEngine:
 
     def profile_stage_names(self):
         path = self.last_count_path()
+        if path == "binned" and self.get_stat("binned_cells") and not self.get_stat("binned_pool"):
+            return ["kb_scatter1_kernel<cells>", "-", "kb_finesort_kernel<cells>", "kb_bucket_kernel"]
         if path == "binned" and self.get_stat("binned_pool"):
             return ["kb_scatter2_kernel", "kb_poolscan+kb_chunklist", "kb_finesort2_kernel", "kb_bucket_kernel"]
         return self._STAGES.get(path, self._STAGES["binned"])

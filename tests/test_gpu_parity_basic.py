@@ -350,3 +350,39 @@ def test_binned_pool_variant_matches_oracle(oracle, k):
         glo, ghi, gcnt = e.export_ge(0)
         assert e.stats()[2] == oracle.count_windows(reads, k) and e.get_stat("replayed_buckets") > 0
         np.testing.assert_array_equal(glo, lo); np.testing.assert_array_equal(ghi, hi); np.testing.assert_array_equal(gcnt, cnt)
+
+
+@pytest.mark.parametrize("k", [31, 47])
+def test_binned_cells_variant_and_its_overflow_fallback(oracle, k):
+    """The default binned pass of big batches has no histogram pass: every (bin, workgroup) pair scatters into a fixed
+    cell (option binned_cells; 2 = at any batch size, for this test).  Skewed input overflows a cell: the later stages
+    then do nothing and the pass is redone with the exact layout -- same result, and the engine stays on the exact path."""
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    rng = np.random.default_rng(1700 + k)
+    genome = rng.integers(0, 4, 60000).astype(np.uint8)
+    reads = rand_reads(rng, 3000, 0, 300, genome=genome) + ["", "N" * 70, "ACGT" * 80]
+    t, (lo, hi, cnt) = oracle_sorted(oracle, k, reads)
+    with KmerEngine(k, capacity_hint=1 << 13) as e:
+        e.set_option("force_path", 2); e.set_option("binned_cells", 2)
+        half = len(reads) // 2
+        e.count(ReadStream.from_strings(reads[:half])); e.count(ReadStream.from_strings(reads[half:]))
+        assert e.get_stat("binned_cells") == 2 and e.get_stat("binned_passes") == 2
+        glo, ghi, gcnt = e.export_ge(0)
+        assert e.stats()[2] == oracle.count_windows(reads, k)
+        np.testing.assert_array_equal(glo, lo); np.testing.assert_array_equal(ghi, hi); np.testing.assert_array_equal(gcnt, cnt)
+    # 4.8 M positions of one repeated read: every workgroup takes two slabs (more slabs than CUs) whose 32 K equal
+    # windows fall into ONE bin -- twice what a cell holds
+    heavy = reads[:500] + ["A" * 300] * 16000
+    t2, (lo2, hi2, cnt2) = oracle_sorted(oracle, k, heavy)
+    with KmerEngine(k, capacity_hint=1 << 14) as e:
+        e.set_option("force_path", 2); e.set_option("binned_cells", 2)
+        e.count(ReadStream.from_strings(heavy))
+        assert e.get_stat("binned_cells") == 0                    # fell back, and stays there
+        glo, ghi, gcnt = e.export_ge(0)
+        assert e.stats()[2] == oracle.count_windows(heavy, k)
+        np.testing.assert_array_equal(glo, lo2); np.testing.assert_array_equal(gcnt, cnt2)
+        e.count(ReadStream.from_strings(reads[:300]))
+        t3 = oracle.OracleTable(k, 1 << 12).count_reads(heavy).count_reads(reads[:300])
+        l3, h3, c3 = t3.export_ge(0)
+        glo, ghi, gcnt = e.export_ge(0)
+        np.testing.assert_array_equal(glo, l3); np.testing.assert_array_equal(gcnt, c3)
