@@ -77,6 +77,8 @@ struct KbPlan {
     uint32_t key_parts, key_part;   // KdfTable::key_parts: windows of other key-space slices are dropped in A0 / A1
     uint32_t dbg;           // experiments only (bucket kernel, plain-loop variant): 1 skip LDS insert, 4 skip write-back
     uint32_t cells;         // 1: the partition was built without a histogram pass (fixed cells); the windows A1 counted wait in totals[5]
+    uint32_t cell_stride;   // cells: entries from one cell's base to the next (CHUNK + a pad: cells that are exactly 128 KB apart
+                            // advance in lockstep through the same HBM channels)
 };
 
 // device scratch shared by the kernels of one pass
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
     for (int i = threadIdx.x; i < nb; i += KB_THREADS) {
         hist[i] = 0;
         if constexpr (CELLS) {
-            const unsigned long long st = ((unsigned long long)i * gridDim.x + blockIdx.x) * KbCfg<KW>::CHUNK;
+            const unsigned long long st = ((unsigned long long)i * gridDim.x + blockIdx.x) * plan.cell_stride;
             gcur[i] = st; gend[i] = st + KbCfg<KW>::CHUNK;
         } else {
             const unsigned long long st = s.bin_start[i] + s.wg_base[(uint64_t)blockIdx.x * nb + i];
@@ -324,7 +326,16 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
         }
     }
     __syncthreads();
-    const uint64_t slab0 = (uint64_t)blockIdx.x * slabs_per_wg;
+    // CELLS: the workgroups are persistent (one per CU) and CLAIM batches of slabs_per_wg slabs from a counter, so a CU
+    // that runs slower takes fewer batches (a static split ran as long as the slowest CU: +20 % on the narrow scatter)
+    uint64_t slab0 = (uint64_t)blockIdx.x * slabs_per_wg;
+    auto claim = [&]() {
+        if (threadIdx.x == 0) wsum[28] = (uint32_t)atomicAdd(&s.totals[6], 1ull);
+        __syncthreads();
+        slab0 = (uint64_t)wsum[28] * slabs_per_wg;
+        __syncthreads();
+    };
+    if constexpr (CELLS) claim();
     constexpr int GL = 2 * WPT;                                         // lanes that copy one bin's run = its mean length (wide keys: 16 lanes instead of 32 took A1 from 8.9 to 7.9 ms)
     const int half = threadIdx.x / GL, lane32 = threadIdx.x % GL;
     constexpr int NHALF = KB_THREADS / GL;
@@ -333,9 +344,10 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
     // copy-out + cursor update.  The next slab's input words are fetched before
     // the current slab is processed, so waves do not reach the first barrier
     // skewed by global-load latency.
+    for (;;) {
+    if (slab0 * TILES_PER_SLAB >= n_tiles) break;                      // uniform
     KbWindows<KW> win;
-    if (slab0 * TILES_PER_SLAB < n_tiles)
-        win.load(packed, invalid, slab0 * TILES_PER_SLAB + threadIdx.x / TPT, n_tiles, threadIdx.x % TPT, k);
+    win.load(packed, invalid, slab0 * TILES_PER_SLAB + threadIdx.x / TPT, n_tiles, threadIdx.x % TPT, k);
     for (uint32_t sl = 0; sl < slabs_per_wg; ++sl) {
         if ((slab0 + sl) * TILES_PER_SLAB >= n_tiles) break;          // uniform
         KbWindows<KW> nxt;
@@ -413,10 +425,13 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
         kb_lds_barrier();                                               // B4: hist is zero, image free (stores still draining)
         win = nxt;
     }
+    if constexpr (!CELLS) break;
+    claim();
+    }
     if constexpr (CELLS) {
         for (int i = threadIdx.x; i < nb; i += KB_THREADS) {
             const unsigned long long chunk = (unsigned long long)i * gridDim.x + blockIdx.x;
-            s.hist_wg[chunk] = (uint32_t)(gcur[i] - chunk * KbCfg<KW>::CHUNK);
+            s.hist_wg[chunk] = (uint32_t)(gcur[i] - chunk * plan.cell_stride);
         }
         if (threadIdx.x == 0) {
             // not into ctl->windows yet: if a cell overflowed somewhere the pass is redone (kernel C adds totals[5])
@@ -431,7 +446,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_cellscan_kernel(KbPlan plan, Kb
     const int nb = 1 << plan.c1;
     for (int i = threadIdx.x; i <= nb; i += KB_THREADS) { s.chunk_first[i] = (unsigned long long)i * n_wg; s.bin_start[i] = (unsigned long long)i * n_wg * chunk_entries; }
     if (threadIdx.x == 0) {
-        s.totals[0] = 0; s.totals[1] = (unsigned long long)nb * n_wg; s.totals[2] = 0; s.totals[3] = 0; s.totals[5] = 0;
+        s.totals[0] = 0; s.totals[1] = (unsigned long long)nb * n_wg; s.totals[2] = 0; s.totals[3] = 0; s.totals[5] = 0; s.totals[6] = 0;
         for (int i = 9; i < 16; ++i) s.totals[i] = 0;             // (totals[8] holds failed_flag: the host cleared it)
     }
 }
@@ -454,7 +469,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_finesort_kernel(KbPlan plan, Kb
     if (CELLS && s.failed_flag[0]) return;                  // a cell overflowed: the host redoes the pass, nothing may be used
     if (chunk >= s.totals[1]) return;                       // the grid covers the largest possible number of chunks
     if (CELLS) {
-        if (threadIdx.x == 0) { sh_start = chunk * (unsigned long long)CHUNK; sh_len = s.hist_wg[chunk]; }
+        if (threadIdx.x == 0) { sh_start = chunk * (unsigned long long)plan.cell_stride; sh_len = s.hist_wg[chunk]; }
     } else
     if (threadIdx.x == 0) {
         // locate the coarse bin of this chunk: chunk_first is ascending
@@ -933,7 +948,7 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
             if (threadIdx.x < KB_C_RUNS && j < j1) {
                 const uint32_t r0 = s.chunk_off[j * plan.off_stride + f], r1 = s.chunk_off[j * plan.off_stride + f + 1];
                 len = r1 - r0;
-                const unsigned long long cs = bstart + (j - j0) * (unsigned long long)CHUNK;      // first entry of the chunk
+                const unsigned long long cs = bstart + (j - j0) * (unsigned long long)(plan.cells ? plan.cell_stride : (uint32_t)CHUNK);      // first entry of the chunk
                 if constexpr (KW == 2) {                      // wide: word index of the run's lo words; the hi words follow the chunk's lo words
                     const unsigned long long left = bend - cs;
                     hioff = (uint32_t)(left < (unsigned long long)CHUNK ? left : (unsigned long long)CHUNK);

@@ -405,7 +405,9 @@ struct kdf_engine {
     uint32_t opt_binned_filtered_min_log2cap = 23;   // count --if goes binned from 2^23 slots (measured crossover)
     int opt_force_path = 0;                          // 0 auto, 1 direct, 2 binned, 3 super-k-mer (kdf_sk.h)
     uint32_t opt_sk_min_k = 20;                      // auto (option sk_auto): narrow keys from this k on take the super-k-mer path
-    int opt_binned_cells = 1;                        // binned path: no histogram pass, fixed (bin, workgroup) cells; falls back to A0 + A1 when a cell overflows
+    int opt_binned_cells = 0;                        // binned path, opt-in (2): no histogram pass, fixed (bin, workgroup) cells; falls back to A0 + A1 when
+                                                     // a cell overflows.  Measured at 10 M reads: k = 63 26.5 -> 24.3 ms, k = 31 14.3 -> 14.6 ms, and only
+                                                     // when the batch fills the cells to 50-80 %: not a default
     bool cells_overflowed = false;                   // sticky: this engine's input is too skewed for fixed cells
     int opt_binned_pool = 0;                         // binned path: 1 = pool scatter without the histogram pass (measured SLOWER: 6.4 ms
                                                      // against A0 + A1 = 5.9 ms, the scatter sits at the 128-VGPR limit), 0 = A0 + A1 + B
@@ -735,20 +737,22 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     const uint64_t nb_table = 1ull << (plan.c1 + plan.c2 + plan.sub_bits);
     const size_t failed_bytes = (size_t)((nb_table + 31) / 32) * 4;
     const int nbins = 1 << plan.c1;
-    // cells: wide keys by default (measured at 10 M reads: k = 63 26.2 -> 24.3 ms; k = 31 14.3 -> 14.6 ms, where the
-    // emptier chunks cost B and C more than the histogram pass saves); option value 2 = any key width and batch size
-    const bool cells = h->opt_binned_cells && !h->opt_binned_pool && !force_exact && !h->cells_overflowed &&
-                       (h->opt_binned_cells > 1 || (KW == 2 && n_tiles * KDF_TILE >= (1ull << 26)));
+    bool cells = h->opt_binned_cells > 1 && !h->opt_binned_pool && !force_exact && !h->cells_overflowed;
+    {   // ... and only when a cell is expected to stay below 90 % even if every position were a window (few bins = a small table)
+        const uint64_t ns = (n_tiles + (KB_THREADS / TPT) - 1) / (KB_THREADS / TPT);
+        const uint64_t wgs = std::min<uint64_t>((ns + 3) / 4, (uint64_t)h->n_cu);
+        if (n_tiles * KDF_TILE > wgs * (uint64_t)(1 << plan.c1) * (uint64_t)(CHUNK * 9 / 10)) cells = false;
+    }
     plan.cells = cells ? 1u : 0u;
     if (cells) {
         // ---- no histogram pass: every (bin, workgroup) owns a cell of CHUNK entries; A1 fills the cells, B sorts each
         // cell in place, kernel C reads them as the chunks of the bins
         const uint64_t n_slabs = (n_tiles + (KB_THREADS / TPT) - 1) / (KB_THREADS / TPT);
-        const uint32_t n_wg = (uint32_t)std::min<uint64_t>(n_slabs, (uint64_t)h->n_cu);
-        const uint32_t slabs_per_wg = (uint32_t)((n_slabs + n_wg - 1) / n_wg);
-        const unsigned grid_a = (unsigned)((n_slabs + slabs_per_wg - 1) / slabs_per_wg);
+        const uint32_t slabs_per_wg = 4;                                                    // slabs per claimed batch
+        const unsigned grid_a = (unsigned)std::min<uint64_t>((n_slabs + slabs_per_wg - 1) / slabs_per_wg, (uint64_t)h->n_cu);   // persistent: one per CU
         const uint64_t n_cells = (uint64_t)grid_a * nbins;
-        if ((rc = kb_reserve(h, 0, n_cells * CHUNK * 8 * KW))) return rc;
+        plan.cell_stride = (uint32_t)CHUNK + 528;               // 33 cache lines (narrow) past the 128 KB: consecutive cells start on different channels
+        if ((rc = kb_reserve(h, 0, n_cells * plan.cell_stride * 8 * KW))) return rc;
         if ((rc = kb_reserve(h, 2, n_cells * (size_t)plan.off_stride * 4))) return rc;
         if ((rc = kb_reserve(h, 3, failed_bytes))) return rc;
         if ((rc = kb_reserve(h, 4, n_cells * 4))) return rc;
@@ -756,7 +760,7 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
         s.chunk_off = (uint32_t *)h->kb_buf[2]; s.failed = (uint32_t *)h->kb_buf[3]; s.hist_wg = (uint32_t *)h->kb_buf[4];
         HIPCHK(h, hipMemsetAsync(s.failed, 0, failed_bytes, h->stream));
         HIPCHK(h, hipMemsetAsync(s.failed_flag, 0, 4, h->stream));
-        hipLaunchKernelGGL(kb_cellscan_kernel, dim3(1), dim3(KB_THREADS), 0, h->stream, plan, s, (uint32_t)CHUNK, (uint32_t)grid_a);
+        hipLaunchKernelGGL(kb_cellscan_kernel, dim3(1), dim3(KB_THREADS), 0, h->stream, plan, s, plan.cell_stride, (uint32_t)grid_a);
         const bool sliced = plan.key_parts > 1;
         if (sliced) hipLaunchKernelGGL((kb_scatter1_kernel<KW, true, true>), dim3(grid_a), dim3(KB_THREADS), lds_a1, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg, h->ctl);
         else hipLaunchKernelGGL((kb_scatter1_kernel<KW, false, true>), dim3(grid_a), dim3(KB_THREADS), lds_a1, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg, h->ctl);

@@ -362,7 +362,7 @@ def test_binned_cells_variant_and_its_overflow_fallback(oracle, k):
     genome = rng.integers(0, 4, 60000).astype(np.uint8)
     reads = rand_reads(rng, 3000, 0, 300, genome=genome) + ["", "N" * 70, "ACGT" * 80]
     t, (lo, hi, cnt) = oracle_sorted(oracle, k, reads)
-    with KmerEngine(k, capacity_hint=1 << 13) as e:
+    with KmerEngine(k, capacity_hint=1 << 20) as e:               # (a table with few buckets has few bins: no cells then)
         e.set_option("force_path", 2); e.set_option("binned_cells", 2)
         half = len(reads) // 2
         e.count(ReadStream.from_strings(reads[:half])); e.count(ReadStream.from_strings(reads[half:]))
@@ -374,7 +374,7 @@ def test_binned_cells_variant_and_its_overflow_fallback(oracle, k):
     # windows fall into ONE bin -- twice what a cell holds
     heavy = reads[:500] + ["A" * 300] * 16000
     t2, (lo2, hi2, cnt2) = oracle_sorted(oracle, k, heavy)
-    with KmerEngine(k, capacity_hint=1 << 14) as e:
+    with KmerEngine(k, capacity_hint=1 << 22) as e:
         e.set_option("force_path", 2); e.set_option("binned_cells", 2)
         e.count(ReadStream.from_strings(heavy))
         assert e.get_stat("binned_cells") == 0                    # fell back, and stays there
