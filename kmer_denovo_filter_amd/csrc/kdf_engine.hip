@@ -299,16 +299,42 @@ __global__ __launch_bounds__(256) void kdf_sieve_build_kernel(const uint64_t *__
     atomicOr((unsigned long long *)&words[w], (unsigned long long)b);
 }
 
-#define KDF_SV_WQ 128                     // queue entries per wave (drained 64 at a time)
+
+// the sieve over the keys the (hash-layout) table holds NOW: an index that was loaded with kdf_add_pairs or counted has
+// none (kdf_load_filter builds one from the key list)
 template <int KW>
+__global__ __launch_bounds__(256) void kdf_sieve_from_table_kernel(KdfTable t, uint64_t *__restrict__ words, uint64_t wmask) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1ull << t.log2cap)) return;
+    const uint64_t lo = t.lo[i], hi = KW == 2 ? t.hi[i] : 0;
+    if ((KW == 1 ? lo : hi) == KDF_EMPTY) return;
+    uint64_t w, b;
+    kdf_sieve_bits(kdf_hash(lo, hi), wmask, w, b);
+    atomicOr((unsigned long long *)&words[w], (unsigned long long)b);
+}
+
+#define KDF_SV_WQ 128                     // queue entries per wave (drained 64 at a time)
+#define KDF_SV_LDS_WORDS 8192             // a sieve of up to 64 KB is copied into LDS by every (persistent) workgroup:
+                                          // filters of up to 64 K keys (VCF mode, Module 3) then cost no L2 request per window
+// SCAN: the Module-3 probe (kdf_scan_reads_dev) through the same sieve: a survivor that is stored with count > 0 sets its
+// window's bit in hit_bits (zeroed by the host first); nothing is counted.
+template <int KW, bool IN_LDS = false, bool SCAN = false>
 __global__ __launch_bounds__(KB_THREADS) void kdf_sieve_count_kernel(
     const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid, uint64_t n_tiles, int k,
-    KdfTable t, KdfCtl *ctl, KdfSieve sv, uint32_t slabs_per_wg)
+    KdfTable t, KdfCtl *ctl, KdfSieve sv, uint32_t slabs_per_wg, unsigned long long *__restrict__ hit_bits = nullptr)
 {
     constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT;
     constexpr uint32_t TILES_PER_SLAB = KB_THREADS / TPT;
     __shared__ uint64_t qlo[(KB_THREADS / 64) * KDF_SV_WQ];
     __shared__ uint64_t qhi[KW == 2 ? (KB_THREADS / 64) * KDF_SV_WQ : 1];
+    __shared__ uint64_t lsv[IN_LDS ? KDF_SV_LDS_WORDS : 1];
+    __shared__ uint32_t qpos[SCAN ? (KB_THREADS / 64) * KDF_SV_WQ : 1];       // SCAN: stream position of the queued window (< 2^32: host-checked)
+    uint32_t *wqpos = qpos + (SCAN ? (threadIdx.x >> 6) * KDF_SV_WQ : 0);
+    if constexpr (IN_LDS) {
+        for (uint32_t i = threadIdx.x; i <= (uint32_t)sv.wmask; i += KB_THREADS) lsv[i] = sv.words[i];
+        __syncthreads();
+    }
+    const uint64_t *const svw = IN_LDS ? lsv : sv.words;
     uint64_t *wqlo = qlo + (threadIdx.x >> 6) * KDF_SV_WQ, *wqhi = qhi + (KW == 2 ? (threadIdx.x >> 6) * KDF_SV_WQ : 0);
     const int lane = threadIdx.x & 63;
     uint32_t wq_n = 0, nwin = 0, claimed = 0;
@@ -317,9 +343,16 @@ __global__ __launch_bounds__(KB_THREADS) void kdf_sieve_count_kernel(
     auto drain = [&](uint32_t from, uint32_t cnt) {
         const bool todo = (uint32_t)lane < cnt;
         const uint64_t klo = todo ? wqlo[from + lane] : 0, khi = (KW == 2 && todo) ? wqhi[from + lane] : 0;
-        const uint64_t slot = kdf_home(t, kdf_hash(klo, khi));
-        if constexpr (KW == 1) { if (todo && !kdf_add_narrow<false>(t, klo, 1u, slot, t.lo[slot], claimed)) full = true; }
-        else { if (!kdf_add_wide<false>(t, todo, klo, khi, 1u, slot, claimed)) full = true; }
+        if constexpr (SCAN) {
+            if (todo) {
+                const uint64_t sl = KW == 1 ? kdf_find_narrow(t, klo) : kdf_find_wide(t, klo, khi);
+                if (sl != ~0ull && t.cnt[sl] != 0) { const uint32_t p = wqpos[from + lane]; atomicOr(&hit_bits[p >> 6], 1ull << (p & 63)); }
+            }
+        } else {
+            const uint64_t slot = kdf_home(t, kdf_hash(klo, khi));
+            if constexpr (KW == 1) { if (todo && !kdf_add_narrow<false>(t, klo, 1u, slot, t.lo[slot], claimed)) full = true; }
+            else { if (!kdf_add_wide<false>(t, todo, klo, khi, 1u, slot, claimed)) full = true; }
+        }
     };
     const uint64_t slab0 = (uint64_t)blockIdx.x * slabs_per_wg;
     for (uint32_t sl = 0; sl < slabs_per_wg; ++sl) {
@@ -339,7 +372,7 @@ __global__ __launch_bounds__(KB_THREADS) void kdf_sieve_count_kernel(
                 uint64_t lo, hi; win.key(u0 + u, lo, hi);
                 const uint64_t hsh = kdf_hash(lo, hi);
                 hb[u] = (uint32_t)hsh & 0xFFFu;
-                w[u] = sv.words[(hsh >> 12) & sv.wmask];
+                w[u] = svw[(hsh >> 12) & sv.wmask];
             }
 #pragma unroll
             for (int u = 0; u < HB; ++u) {
@@ -347,7 +380,10 @@ __global__ __launch_bounds__(KB_THREADS) void kdf_sieve_count_kernel(
                 const unsigned long long mk = __ballot(ok);
                 if (mk) {
                     const uint32_t at = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-                    if (ok) { uint64_t lo, hi; win.key(u0 + u, lo, hi); wqlo[at] = lo; if constexpr (KW == 2) wqhi[at] = hi; }
+                    if (ok) {
+                        uint64_t lo, hi; win.key(u0 + u, lo, hi); wqlo[at] = lo; if constexpr (KW == 2) wqhi[at] = hi;
+                        if constexpr (SCAN) wqpos[at] = (uint32_t)(tile * 64 + (threadIdx.x % TPT) * WPT + u0 + u);
+                    }
                     wq_n += (uint32_t)__popcll(mk);
                     if (wq_n >= 64) { wq_n -= 64; drain(wq_n, 64); }        // (wave-uniform)
                 }
@@ -359,7 +395,7 @@ __global__ __launch_bounds__(KB_THREADS) void kdf_sieve_count_kernel(
     uint32_t n = nwin;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
-    if (lane == 0 && n) atomicAdd(&ctl->windows[((blockIdx.x * 16 + (threadIdx.x >> 6)) % KDF_SHARDS) * 16], (unsigned long long)n);
+    if (!SCAN && lane == 0 && n) atomicAdd(&ctl->windows[((blockIdx.x * 16 + (threadIdx.x >> 6)) % KDF_SHARDS) * 16], (unsigned long long)n);
 }
 
 __global__ void kdf_ctl_reduce_kernel(KdfCtl *ctl, unsigned long long *out3) {
@@ -1315,6 +1351,7 @@ static bool use_binned(const kdf_engine *h, uint64_t n_bases, bool filtered) {
 // at load <= 0.8; the table doubles when fewer than cap/8 positions fit.
 static int count_insert_dev(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases) {
     if (h->filter_mode) return fail(h, KDF_ERR_STATE, "kdf_count_reads: a filter is loaded; call kdf_clear first");
+    h->sieve_valid = false;                          // new keys join the table: a sieve built from it earlier (scan) is stale
     h->t.key_parts = h->opt_key_parts; h->t.key_part = h->opt_key_part;       // (tables are re-created by reserve / rehash: set per call)
     const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
     if (h->opt_force_path == 3 && (h->kw != 1 || h->k < SK_MIN_K))
@@ -1378,8 +1415,11 @@ static int count_filtered_dev(kdf_engine *h, const uint64_t *d_packed, const uin
         KdfSieve sv{h->sieve, h->sieve_words - 1};
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (h->prof) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, h->stream); }
-        if (h->kw == 1) hipLaunchKernelGGL(kdf_sieve_count_kernel<1>, dim3(grid), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->k, h->t, h->ctl, sv, spw);
-        else hipLaunchKernelGGL(kdf_sieve_count_kernel<2>, dim3(grid), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->k, h->t, h->ctl, sv, spw);
+        const bool in_lds = h->sieve_words <= KDF_SV_LDS_WORDS && !(h->opt_debug_flags & 2048);
+        if (h->kw == 1 && in_lds) hipLaunchKernelGGL((kdf_sieve_count_kernel<1, true>), dim3(grid), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->k, h->t, h->ctl, sv, spw);
+        else if (h->kw == 1) hipLaunchKernelGGL((kdf_sieve_count_kernel<1, false>), dim3(grid), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->k, h->t, h->ctl, sv, spw);
+        else if (in_lds) hipLaunchKernelGGL((kdf_sieve_count_kernel<2, true>), dim3(grid), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->k, h->t, h->ctl, sv, spw);
+        else hipLaunchKernelGGL((kdf_sieve_count_kernel<2, false>), dim3(grid), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->k, h->t, h->ctl, sv, spw);
         if (h->prof) { (void)hipEventRecord(e1, h->stream); h->prof_ev.emplace_back(e0, e1); h->prof_tiles.push_back(n_tiles); }
         HIPCHK(h, hipGetLastError());
         h->last_path = 3;
@@ -1544,6 +1584,34 @@ int kdf_count_reads(kdf_engine *h, const uint64_t *packed, const uint64_t *inval
     return count_insert_dev(h, dp, dm, n_bases);
 }
 
+// Size, allocate and zero the membership sieve for n keys (sieve_valid says whether there is one).  Every window costs
+// one random 8-byte read of it, i.e. one L2 request: measured on the parent-filter workload (1.49 G windows, 1.9 M keys)
+// 8.3 ms with a 2 MB sieve, 9.1 ms with 4 MB, 16 ms with 8 MB, 24 ms with 16 MB -- it must sit in the 4 MB L2 of every XCD
+// beside the streamed reads.  So: the most bits per key out of 32 / 16 / 8 that keep it within 2 MB, 8 bits per key beyond
+// that, and no sieve (the binned path) once even that passes 16 MB.  Up to 64 K keys it is shrunk to the 64 KB that the
+// kernel copies into LDS (no L2 request per window at all: ~700 Gk-mer/s for the filters of VCF mode and Module 3).
+static int sieve_prepare(kdf_engine *h, uint64_t n) {
+    h->sieve_valid = false;
+    uint64_t bpk = h->opt_sieve_bits ? (uint64_t)h->opt_sieve_bits : 32;
+    if (!h->opt_sieve_bits) {
+        while (bpk > 8 && n * bpk > (16ull << 20)) bpk >>= 1;
+        if (n * 8 <= (uint64_t)KDF_SV_LDS_WORDS * 64) while (bpk > 8 && n * bpk > (uint64_t)KDF_SV_LDS_WORDS * 64) bpk >>= 1;
+    }
+    if (!(h->opt_sieve_bits || n * bpk <= (128ull << 20))) return KDF_OK;
+    const uint64_t bits = n * bpk;
+    const uint64_t words = std::max<uint64_t>(1024, 1ull << log2ceil((bits + 63) / 64));
+    if (h->sieve_alloc < words) {
+        if (h->sieve) (void)hipFree(h->sieve);
+        h->sieve = nullptr; h->sieve_alloc = 0;
+        HIPCHK(h, hipMalloc((void **)&h->sieve, words * 8));
+        h->sieve_alloc = words;
+    }
+    h->sieve_words = words;
+    HIPCHK(h, hipMemsetAsync(h->sieve, 0, words * 8, h->stream));
+    h->sieve_valid = true;
+    return KDF_OK;
+}
+
 // the table becomes exactly the n keys at d_lo / d_hi (device arrays) with count 0
 static int load_filter_core(kdf_engine *h, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t n) {
     int rc;
@@ -1573,30 +1641,11 @@ static int load_filter_core(kdf_engine *h, const uint64_t *d_lo, const uint64_t 
         if ((rc = ctl_sync(h, &full))) return rc;
         if (full) return fail(h, KDF_ERR_TABLE_FULL, "kdf_load_filter: bucket overflow");
     }
-    // The membership sieve over the same keys.  Every window costs one random 8-byte read of it, i.e. one L2 request:
-    // measured on the parent-filter workload (1.49 G windows, 1.9 M keys) 8.3 ms with a 2 MB sieve, 9.1 ms with 4 MB,
-    // 16 ms with 8 MB, 24 ms with 16 MB -- it must sit in the 4 MB L2 of every XCD beside the streamed reads.  So:
-    // the most bits per key out of 32 / 16 / 8 that keep it within 2 MB, 8 bits per key beyond that, and no sieve
-    // (the binned path) once even that passes 16 MB.
-    h->sieve_valid = false;
-    uint64_t bpk = h->opt_sieve_bits ? (uint64_t)h->opt_sieve_bits : 32;
-    if (!h->opt_sieve_bits) while (bpk > 8 && n * bpk > (16ull << 20)) bpk >>= 1;
-    if (h->opt_sieve_bits || n * bpk <= (128ull << 20)) {
-        const uint64_t bits = n * bpk;
-        const uint64_t words = std::max<uint64_t>(1024, 1ull << log2ceil((bits + 63) / 64));
-        if (h->sieve_alloc < words) {
-            if (h->sieve) (void)hipFree(h->sieve);
-            h->sieve = nullptr; h->sieve_alloc = 0;
-            HIPCHK(h, hipMalloc((void **)&h->sieve, words * 8));
-            h->sieve_alloc = words;
-        }
-        h->sieve_words = words;
-        HIPCHK(h, hipMemsetAsync(h->sieve, 0, words * 8, h->stream));
-        if (n == 0) {}                                           // an empty filter: the all-zero sieve lets nothing through
-        else if (h->kw == 1) hipLaunchKernelGGL(kdf_sieve_build_kernel<1>, dim3(blocks), dim3(256), 0, h->stream, d_lo, (const uint64_t *)nullptr, n, h->sieve, words - 1);
-        else hipLaunchKernelGGL(kdf_sieve_build_kernel<2>, dim3(blocks), dim3(256), 0, h->stream, d_lo, d_hi, n, h->sieve, words - 1);
+    if ((rc = sieve_prepare(h, n)) != KDF_OK) return rc;
+    if (h->sieve_valid && n) {
+        if (h->kw == 1) hipLaunchKernelGGL(kdf_sieve_build_kernel<1>, dim3(blocks), dim3(256), 0, h->stream, d_lo, (const uint64_t *)nullptr, n, h->sieve, h->sieve_words - 1);
+        else hipLaunchKernelGGL(kdf_sieve_build_kernel<2>, dim3(blocks), dim3(256), 0, h->stream, d_lo, d_hi, n, h->sieve, h->sieve_words - 1);
         HIPCHK(h, hipGetLastError());
-        h->sieve_valid = true;
     }
     return KDF_OK;
 }
@@ -1906,6 +1955,38 @@ int kdf_scan_reads_dev(kdf_engine *h, const void *d_packed, const void *d_invali
     HIPCHK(h, hipSetDevice(h->device));
     { int rc0 = materialize(h); if (rc0) return rc0; }
     const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
+    if (!h->t.sk && h->opt_force_path != 1 && n_tiles * KDF_TILE < (1ull << 32)) {
+        // through the membership sieve (section 3.5 of DESIGN.md): an index that was loaded with kdf_add_pairs has none yet
+        int rc;
+        if (!h->sieve_valid) {
+            if ((rc = ctl_sync(h, nullptr))) return rc;
+            if ((rc = sieve_prepare(h, h->distinct))) return rc;
+            if (h->sieve_valid) {
+                const unsigned tb = (unsigned)((h->cap + 255) / 256);
+                if (h->kw == 1) hipLaunchKernelGGL(kdf_sieve_from_table_kernel<1>, dim3(tb), dim3(256), 0, h->stream, h->t, h->sieve, h->sieve_words - 1);
+                else hipLaunchKernelGGL(kdf_sieve_from_table_kernel<2>, dim3(tb), dim3(256), 0, h->stream, h->t, h->sieve, h->sieve_words - 1);
+                HIPCHK(h, hipGetLastError());
+            }
+        }
+        if (h->sieve_valid) {
+            HIPCHK(h, hipMemsetAsync(d_hit_bits, 0, n_tiles * 8, h->stream));
+            const int WPT = h->kw == 1 ? KbCfg<1>::WPT : KbCfg<2>::WPT;
+            const uint64_t tiles_per_slab = KB_THREADS / (64 / WPT);
+            const uint64_t n_slabs = (n_tiles + tiles_per_slab - 1) / tiles_per_slab;
+            const uint32_t n_wg = (uint32_t)std::min<uint64_t>(n_slabs, (uint64_t)h->n_cu * 8);
+            const uint32_t spw = (uint32_t)((n_slabs + n_wg - 1) / n_wg);
+            const unsigned grid = (unsigned)((n_slabs + spw - 1) / spw);
+            KdfSieve sv{h->sieve, h->sieve_words - 1};
+            unsigned long long *hb = (unsigned long long *)d_hit_bits;
+            const bool in_lds = h->sieve_words <= KDF_SV_LDS_WORDS;
+#define SV_SCAN(KWV, L) hipLaunchKernelGGL((kdf_sieve_count_kernel<KWV, L, true>), dim3(grid), dim3(KB_THREADS), 0, h->stream, (const uint64_t *)d_packed, (const uint64_t *)d_invalid, n_tiles, h->k, h->t, h->ctl, sv, spw, hb)
+            if (h->kw == 1) { if (in_lds) SV_SCAN(1, true); else SV_SCAN(1, false); }
+            else { if (in_lds) SV_SCAN(2, true); else SV_SCAN(2, false); }
+#undef SV_SCAN
+            HIPCHK(h, hipGetLastError());
+            return KDF_OK;
+        }
+    }
     launch_stream<MODE_SCAN>(h, (const uint64_t *)d_packed, (const uint64_t *)d_invalid, 0, n_tiles, (uint64_t *)d_hit_bits);
     HIPCHK(h, hipGetLastError());
     return KDF_OK;
