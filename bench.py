@@ -219,10 +219,15 @@ def run_count(args, world, rank, local_rank):
             merger.count_local(s.packed, s.invalid, s.n_bases)
         torch.cuda.synchronize()
         tm = time.perf_counter()
-        n = merger.merge(3)
+        merger.exchange()                                # every pair to its owner, summed there (the `jellyfish merge`)
         torch.cuda.synchronize()
         merge_ms[0] += (time.perf_counter() - tm) * 1e3
-        return n
+        # the same materialised dump as at N = 1, each owner its share of the keys
+        n_own = owner_eng.export_ge_dev(3, out_lo.data_ptr(), out_hi.data_ptr() if out_hi is not None else None,
+                                        out_cnt.data_ptr(), out_cap)
+        t = torch.tensor([n_own], dtype=torch.int64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(t.item())
 
     def barrier():
         if world > 1:
@@ -310,9 +315,11 @@ def run_count(args, world, rank, local_rank):
             "windows_rank0": windows, "distinct_rank0_local": distinct, "kmers_ge3": int(n_ge3),
             "table_slots": eng.stats()[0], "count_path": eng.last_count_path(),
             "multi_gpu": None if world == 1 else {
-                "job": "every step: clear, count the rank's batches locally, ONE owner-partitioned all-to-all of (key,count) pairs "
-                       "+ owner-side sum + global dump -L 3 count, all inside the timed region",
+                "job": "every step: clear, count the rank's batches locally, hash-ordered dump by owner, ONE packed all-to-all of "
+                       "(key,count) pairs, owner-side LDS bucket merge, materialised dump -L 3 of every owner's keys, all inside "
+                       "the timed region",
                 "merge_ms_per_step": round(merge_ms[0] / steps, 3), "exchanged_pairs_rank0": merger.last_exchange_pairs,
+                "owner_merge": {0: None, 1: "lds_buckets", 2: "global_atomics"}[owner_eng.get_stat("last_merge_path")],
             },
         },
         "roofline": {

@@ -133,6 +133,15 @@ int kdf_add_pairs(kdf_engine *h, const uint64_t *keys_lo, const uint64_t *keys_h
                   const uint32_t *counts, uint64_t n);
 int kdf_add_pairs_dev(kdf_engine *h, const void *d_keys_lo, const void *d_keys_hi,
                       const void *d_counts, uint64_t n);
+/* The owner's half of the multi-GPU merge: `nseg` (<= 64 for the fast path) segments of pairs in HBM, one per source
+ * rank, summed into the table in one call (d_keys_lo / d_keys_hi / d_counts / n are HOST arrays of nseg device
+ * pointers / lengths; d_keys_hi may be NULL for k <= 32).  When every segment is grouped by this table's buckets in
+ * ascending order -- what kdf_export_parts_dev writes -- each bucket is merged in LDS by one workgroup and written
+ * once (the test runs on the device; any other order is merged through global atomics, same result).  An owner table
+ * should be created with option "hash_shift" = floor(log2(world)): its home slots then ignore the hash bits that name
+ * the owner, so the table is used over its whole length and the senders' order is its own. */
+int kdf_add_pairs_multi_dev(kdf_engine *h, uint32_t nseg, const void *const *d_keys_lo,
+                            const void *const *d_keys_hi, const void *const *d_counts, const uint64_t *n);
 
 /* ------------------------------------------------ count --if (filter) ---- */
 
@@ -194,8 +203,11 @@ int kdf_export_ge_dev(kdf_engine *h, uint32_t min_count, void *d_keys_lo_out,
  * pair to DEVICE arrays grouped by owner rank, owner(key) = ((hash(key) >> 48) * parts) >> 16
  * with the table's own hash -- so the owners are contiguous slot ranges and no sort or
  * partition pass is needed.  part_counts_out[parts] (host) receives the pairs per owner;
- * part p occupies [sum(counts[0..p)), +counts[p]) of the outputs, unordered inside.
- * parts <= 64; KDF_ERR_STATE when the table is smaller than 2^28 (2^27 wide) slots. */
+ * part p occupies [sum(counts[0..p)), +counts[p]) of the outputs.  The whole dump is in HASH
+ * ORDER (grouped by the top log2cap - 6 hash bits, ascending), which is bucket order in every
+ * owner table of up to 64x this table's slots per owner: kdf_add_pairs_multi_dev merges it
+ * bucket by bucket in LDS.  One stream synchronisation.
+ * parts <= 64; KDF_ERR_STATE when the table is smaller than 2^28 slots. */
 int kdf_export_parts_dev(kdf_engine *h, uint32_t min_count, uint32_t parts, void *d_keys_lo_out,
                          void *d_keys_hi_out, void *d_counts_out, uint64_t cap,
                          uint64_t *part_counts_out, uint64_t *n_out);

@@ -36,6 +36,7 @@ SYMBOLS = [
     ("kdf_count_reads_dev", c_int, [_P, _P, _P, c_uint64]),
     ("kdf_add_pairs", c_int, [_P, _P, _P, _P, c_uint64]),
     ("kdf_add_pairs_dev", c_int, [_P, _P, _P, _P, c_uint64]),
+    ("kdf_add_pairs_multi_dev", c_int, [_P, c_uint32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_uint64)]),
     ("kdf_load_filter", c_int, [_P, _P, _P, c_uint64]),
     ("kdf_load_filter_dev", c_int, [_P, _P, _P, c_uint64]),
     ("kdf_reset_counts", c_int, [_P]),

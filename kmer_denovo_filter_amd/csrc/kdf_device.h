@@ -72,6 +72,10 @@ struct KdfTable {
     // the table the bucket is simply the top bits of h.
     uint32_t sk_c1, sk_c2;
     const uint16_t *sk_assign;
+    // Owner tables of the multi-GPU merge (option "hash_shift"): rank r of 2^w only ever sees keys whose top w hash
+    // bits are r, so the home slot drops them -- the table is used over its whole length, and a dump that arrives in
+    // the sender's slot order is still in this table's slot order.
+    uint32_t hshift;
 };
 
 // Slice of a key from the LOW 16 bits of its hash.  (The multi-GPU owner function uses the TOP bits, which are
@@ -91,7 +95,7 @@ struct KdfCtl {            // device-resident control block (one per engine)
 };
 
 __device__ __forceinline__ uint64_t kdf_home(const KdfTable &t, uint64_t h) {
-    return h >> (64 - t.log2cap);
+    return (h << t.hshift) >> (64 - t.log2cap);
 }
 
 // ---- minimizer-bucketed layout ------------------------------------------------

@@ -14,6 +14,7 @@
 #include "kdf_device.h"
 #include "kdf_binned.h"
 #include "kdf_sk.h"
+#include "kdf_merge.h"
 
 // sorted export lives in kdf_sort.hip (rocPRIM radix sort)
 int kdf_sort_pairs_device(uint64_t *d_lo, uint64_t *d_hi, uint32_t *d_cnt, uint64_t n,
@@ -154,17 +155,13 @@ __global__ __launch_bounds__(256) void kdf_query_kernel(
 template <int KW, bool WRITE>
 __global__ __launch_bounds__(256) void kdf_export_kernel(
     KdfTable t, uint32_t min_count, KdfCtl *ctl, uint64_t *__restrict__ olo,
-    uint64_t *__restrict__ ohi, uint32_t *__restrict__ ocnt, uint64_t out_cap, uint32_t parts)
+    uint64_t *__restrict__ ohi, uint32_t *__restrict__ ocnt, uint64_t out_cap)
 {
     const uint64_t cap = 1ull << t.log2cap;
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint64_t first = wave * (KDF_EXPORT_ROWS * 64);
     if (first >= cap) return;
-    // parts > 0: output grouped by owner rank, owner(key) = ((hash >> 48) * parts) >> 16.  The
-    // top 16 hash bits are the top 16 bits of the home slot and a key never leaves its bucket,
-    // so (host-checked: log2cap - 16 >= max(11, bucket_bits)) all slots of this wave have one owner.
-    const uint32_t part = parts ? (uint32_t)((((first >> (t.log2cap - 16)) & 0xFFFFu) * parts) >> 16) : 0u;
     uint32_t mine = 0;
     if (!WRITE && min_count >= 1 && first + KDF_EXPORT_ROWS * 64 <= cap) {
         // count > 0 implies the slot is occupied: stream the counts array only, 16 B per lane
@@ -192,12 +189,11 @@ __global__ __launch_bounds__(256) void kdf_export_kernel(
     for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
     if (tot == 0) return;
     if (!WRITE) {      // counting pass: no positions needed, spread the adds over 64 lines
-        if (lane == 0) atomicAdd(&ctl->tally[(parts ? part : (uint32_t)(wave % KDF_SHARDS)) * 16], (unsigned long long)tot);
+        if (lane == 0) atomicAdd(&ctl->tally[(uint32_t)(wave % KDF_SHARDS) * 16], (unsigned long long)tot);
         return;
     }
     unsigned long long base = 0;
-    // parts: tally[part] was preloaded with the part's offset and serves as its cursor
-    if (lane == 0) base = parts ? atomicAdd(&ctl->tally[part * 16], (unsigned long long)tot) : atomicAdd(&ctl->cursor, (unsigned long long)tot);
+    if (lane == 0) base = atomicAdd(&ctl->cursor, (unsigned long long)tot);
     base = __shfl(base, 0);
     for (int r = 0; r < KDF_EXPORT_ROWS; ++r) {
         const uint64_t i = first + (uint64_t)r * 64 + lane;
@@ -439,6 +435,7 @@ struct kdf_engine {
     uint64_t opt_binned_max_positions = 1ull << 31;  // longer streams are walked in several binned passes: a pass must add
                                                      // < 2^32 to any slot (kernel C saturates by comparing with the HBM count)
     uint32_t opt_binned_filtered_min_log2cap = 23;   // count --if goes binned from 2^23 slots (measured crossover)
+    uint32_t opt_hash_shift = 0;                     // KdfTable::hshift of the tables this engine creates (owner tables)
     int opt_force_path = 0;                          // 0 auto, 1 direct, 2 binned, 3 super-k-mer (kdf_sk.h)
     uint32_t opt_sk_min_k = 20;                      // auto (option sk_auto): narrow keys from this k on take the super-k-mer path
     int opt_binned_cells = 0;                        // binned path, opt-in (2): no histogram pass, fixed (bin, workgroup) cells; falls back to A0 + A1 when
@@ -447,6 +444,9 @@ struct kdf_engine {
     bool cells_overflowed = false;                   // sticky: this engine's input is too skewed for fixed cells
     int opt_binned_pool = 0;                         // binned path: 1 = pool scatter without the histogram pass (measured SLOWER: 6.4 ms
                                                      // against A0 + A1 = 5.9 ms, the scatter sits at the 128-VGPR limit), 0 = A0 + A1 + B
+    void *merge_buf = nullptr; size_t merge_bytes = 0;   // kdf_merge.h: block counts / offsets of the ordered dump, bucket ranges of a merge
+    uint32_t merge_flag_host = 0;
+    int last_merge_path = 0;                         // 0 none yet, 1 LDS bucket merge launched, 2 plain atomic insert
     void *kp_buf[8] = {nullptr};                     // pool variant: pool, chunk_bin, chunk_pos, chunk_fill, chunk_list, small, pool_ctr
     size_t kp_bytes[8] = {0};
     int opt_sieve_bits = 0;                          // sieve bits per filter key (0: 32 up to 2^20 keys, 16 beyond)
@@ -509,11 +509,12 @@ static uint32_t cap_log2_for(uint64_t n_keys) {
     return std::max<uint32_t>(l, 10);
 }
 
-static int table_alloc(kdf_engine *h, uint32_t log2cap, KdfTable &t) {
+static int table_alloc(kdf_engine *h, uint32_t log2cap, KdfTable &t, bool clear = true) {
     const uint64_t cap = 1ull << log2cap;
     t = KdfTable{};
     t.log2cap = log2cap;
     t.bucket_bits = std::min<uint32_t>(log2cap, h->kw == 1 ? 12 : 11);   // 48 / 40 KB of LDS per bucket
+    t.hshift = h->opt_hash_shift;
     {
         hipError_t e = hipMalloc((void **)&t.lo, cap * 8);
         if (e == hipSuccess && h->kw == 2) e = hipMalloc((void **)&t.hi, cap * 8);
@@ -529,6 +530,7 @@ static int table_alloc(kdf_engine *h, uint32_t log2cap, KdfTable &t) {
                         log2cap, (double)cap * (8.0 * h->kw + 4.0) / 1e9, hipGetErrorString(e));
         }
     }
+    if (!clear) return KDF_OK;                       // the caller keeps the engine's deferred-clear flag set
     HIPCHK(h, hipMemsetAsync(t.lo, 0xFF, cap * 8, h->stream));
     if (h->kw == 2) HIPCHK(h, hipMemsetAsync(t.hi, 0xFF, cap * 8, h->stream));
     HIPCHK(h, hipMemsetAsync(t.cnt, 0, cap * 4, h->stream));
@@ -1248,7 +1250,7 @@ static int sk_passes(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_
 }
 
 static bool use_sk(const kdf_engine *h, uint64_t n_bases) {
-    if (h->kw != 1 || h->k < SK_MIN_K) return false;
+    if (h->kw != 1 || h->k < SK_MIN_K || h->opt_hash_shift) return false;
     if (h->t.sk) return true;                                   // an SK-layout table takes every batch through this path
     if (h->filter_mode || h->distinct != 0) return false;       // layouts change only on an empty table
     if (h->opt_force_path == 3) return true;
@@ -1338,6 +1340,7 @@ static int sk_table_rehash(kdf_engine *h, uint32_t new_log2) {
 }
 
 static bool use_binned(const kdf_engine *h, uint64_t n_bases, bool filtered) {
+    if (h->opt_hash_shift) return false;                       // an owner table: the bins assume home = top hash bits
     if (h->t.log2cap <= h->t.bucket_bits) return false;        // a single bucket: nothing to partition
     if (h->opt_force_path == 1) return false;
     if (h->opt_force_path == 2) return true;
@@ -1504,6 +1507,7 @@ void kdf_destroy(kdf_engine *h) {
     for (int i = 0; i < 6; ++i) if (h->kb_buf[i]) (void)hipFree(h->kb_buf[i]);
     for (int i = 0; i < 16; ++i) if (h->sk_buf[i]) (void)hipFree(h->sk_buf[i]);
     for (int i = 0; i < 8; ++i) if (h->kp_buf[i]) (void)hipFree(h->kp_buf[i]);
+    if (h->merge_buf) (void)hipFree(h->merge_buf);
     if (h->sieve) (void)hipFree(h->sieve);
     if (h->sk_assign) (void)hipFree(h->sk_assign);
     if (h->sk_weights) (void)hipFree(h->sk_weights);
@@ -1685,31 +1689,116 @@ int kdf_reset_counts(kdf_engine *h) {
     return KDF_OK;
 }
 
-// insert-or-add (key, count) pairs resident in HBM; grows the table first so the
-// pairs fit at load <= 0.5 even if all of them are new
-static int add_pairs_dev(kdf_engine *h, const uint64_t *d_lo, const uint64_t *d_hi, const uint32_t *d_cnt, uint64_t n) {
-    if (n == 0) return KDF_OK;
+static int merge_reserve(kdf_engine *h, size_t bytes) {
+    if (h->merge_bytes >= bytes) return KDF_OK;
+    if (h->merge_buf) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->merge_buf); h->merge_buf = nullptr; h->merge_bytes = 0; }
+    HIPCHK(h, hipMalloc(&h->merge_buf, bytes));
+    h->merge_bytes = bytes;
+    return KDF_OK;
+}
+
+// insert-or-add (key, count) pairs resident in HBM, in `nseg` segments (one per source rank of a merge); grows the
+// table first so the pairs fit at load <= 0.5 even if all of them are new.  Hash-layout tables take segments of any
+// order: km_bounds_kernel tests on the device whether every segment is grouped by table bucket (a dump made by
+// kdf_export_parts_dev is) and the LDS bucket merge or the atomic insert runs accordingly -- no host decision.
+#define KDF_MERGE_MIN_PAIRS (1u << 16)
+static int add_pairs_multi(kdf_engine *h, uint32_t nseg, const uint64_t *const *d_lo, const uint64_t *const *d_hi,
+                           const uint32_t *const *d_cnt, const uint64_t *n) {
+    uint64_t total = 0, nmax = 0;
+    bool counts = true;
+    for (uint32_t s = 0; s < nseg; ++s) { total += n[s]; nmax = std::max(nmax, n[s]); if (n[s] && !d_cnt[s]) counts = false; }
+    if (total == 0) return KDF_OK;
     h->sieve_valid = false;                          // keys may join the table that the sieve has not seen
-    int rc = materialize(h);
-    if (rc) return rc;
+    int rc;
     if ((rc = ctl_sync(h, nullptr))) return rc;
-    const uint32_t want = cap_log2_for(h->distinct + n);
-    if (want > h->t.log2cap && (rc = table_rehash(h, want))) return rc;
-    if (h->t.sk) {
-        SkScratch s{};
-        if ((rc = sk_insert_pairs(h, d_lo, d_cnt, n, 0, n, s, true))) return rc;
-        return sk_insert_finish(h, s);
+    const uint32_t want = cap_log2_for(h->distinct + total);
+    if (want > h->t.log2cap) {
+        if (h->lazy_empty && !h->t.sk) {             // nothing to carry over: a new table, still to be cleared
+            KdfTable nt;
+            if ((rc = table_alloc(h, want, nt, false))) return rc;
+            HIPCHK(h, hipStreamSynchronize(h->stream));          // (nothing in flight may still touch the old arrays)
+            table_free(h->t);
+            h->t = nt; h->t.key_parts = h->opt_key_parts; h->t.key_part = h->opt_key_part;
+            h->cap = 1ull << want;
+        } else if ((rc = table_rehash(h, want))) return rc;
     }
-    const unsigned blocks = (unsigned)((n + 255) / 256);
-    if (h->kw == 1)
-        hipLaunchKernelGGL(kdf_insert_keys_kernel<1>, dim3(blocks), dim3(256), 0, h->stream, d_lo, (const uint64_t *)nullptr, d_cnt, n, h->t, h->ctl, 0);
-    else
-        hipLaunchKernelGGL(kdf_insert_keys_kernel<2>, dim3(blocks), dim3(256), 0, h->stream, d_lo, d_hi, d_cnt, n, h->t, h->ctl, 0);
+    if (h->t.sk) {
+        if ((rc = materialize(h))) return rc;
+        for (uint32_t s = 0; s < nseg; ++s) {
+            if (!n[s]) continue;
+            SkScratch sc{};
+            if ((rc = sk_insert_pairs(h, d_lo[s], d_cnt[s], n[s], 0, n[s], sc, true))) return rc;
+            if ((rc = sk_insert_finish(h, sc))) return rc;
+        }
+        return KDF_OK;
+    }
+    const bool lds = counts && total >= KDF_MERGE_MIN_PAIRS && nseg <= KM_MAX_SEGS && nmax < 0xFFFFFFFFull;
+    if (!lds) {
+        if ((rc = materialize(h))) return rc;
+        for (uint32_t s = 0; s < nseg; ++s) {
+            if (!n[s]) continue;
+            const unsigned blocks = (unsigned)((n[s] + 255) / 256);
+            if (h->kw == 1)
+                hipLaunchKernelGGL(kdf_insert_keys_kernel<1>, dim3(blocks), dim3(256), 0, h->stream, d_lo[s], (const uint64_t *)nullptr, d_cnt[s], n[s], h->t, h->ctl, 0);
+            else
+                hipLaunchKernelGGL(kdf_insert_keys_kernel<2>, dim3(blocks), dim3(256), 0, h->stream, d_lo[s], d_hi[s], d_cnt[s], n[s], h->t, h->ctl, 0);
+        }
+        h->last_merge_path = 2;
+    } else {
+        KmSegs sg{};
+        uint32_t m = 0;
+        for (uint32_t s = 0; s < nseg; ++s) {
+            if (!n[s]) continue;
+            sg.lo[m] = d_lo[s]; sg.hi[m] = h->kw == 2 ? d_hi[s] : nullptr; sg.cnt[m] = d_cnt[s]; sg.n[m] = (uint32_t)n[s]; ++m;
+        }
+        sg.nseg = m;
+        const uint32_t nb = (uint32_t)(h->cap >> h->t.bucket_bits);
+        const size_t words = (size_t)m * nb * 2 + 16;
+        if ((rc = merge_reserve(h, words * 4))) return rc;
+        uint32_t *first = (uint32_t *)h->merge_buf, *last = first + (size_t)m * nb, *flag = last + (size_t)m * nb;
+        HIPCHK(h, hipMemsetAsync(h->merge_buf, 0, words * 4, h->stream));
+        const dim3 pg((unsigned)((nmax + 255) / 256), m);
+        const size_t lds_bytes = ((size_t)8 * h->kw + 4) << h->t.bucket_bits;
+        const bool fresh = h->lazy_empty;            // the kernel writes every bucket: it IS the deferred clear
+        by_width(h, [&](auto KWc) {
+            constexpr int KW = decltype(KWc)::value;
+            hipLaunchKernelGGL(km_bounds_kernel<KW>, pg, dim3(256), 0, h->stream, h->t, sg, nb, first, last, flag);
+            if (fresh) hipLaunchKernelGGL((km_merge_kernel<KW, true>), dim3(nb), dim3(KM_THREADS), lds_bytes, h->stream, h->t, sg, nb, first, last, flag, h->ctl);
+            else hipLaunchKernelGGL((km_merge_kernel<KW, false>), dim3(nb), dim3(KM_THREADS), lds_bytes, h->stream, h->t, sg, nb, first, last, flag, h->ctl);
+            hipLaunchKernelGGL(km_insert_guarded_kernel<KW>, pg, dim3(256), 0, h->stream, h->t, sg, flag, h->ctl);
+            return 0;
+        });
+        h->lazy_empty = false;
+        h->last_merge_path = 1;
+        HIPCHK(h, hipMemcpyAsync(&h->merge_flag_host, flag, 4, hipMemcpyDeviceToHost, h->stream));
+    }
     HIPCHK(h, hipGetLastError());
     bool full = false;
     if ((rc = ctl_sync(h, &full))) return rc;
+    if (h->last_merge_path == 1 && h->merge_flag_host) h->last_merge_path = 2;     // a segment was not grouped: the atomic kernel did the work
     if (full) return fail(h, KDF_ERR_TABLE_FULL, "kdf_add_pairs: bucket overflow");
     return KDF_OK;
+}
+
+static int add_pairs_dev(kdf_engine *h, const uint64_t *d_lo, const uint64_t *d_hi, const uint32_t *d_cnt, uint64_t n) {
+    return add_pairs_multi(h, 1, &d_lo, &d_hi, &d_cnt, &n);
+}
+
+int kdf_add_pairs_multi_dev(kdf_engine *h, uint32_t nseg, const void *const *d_keys_lo, const void *const *d_keys_hi,
+                            const void *const *d_counts, const uint64_t *n) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    if (nseg == 0) return KDF_OK;
+    if (!d_keys_lo || !n || !d_counts) return fail(h, KDF_ERR_INVALID, "kdf_add_pairs_multi_dev: NULL pointer");
+    if (h->kw == 2 && !d_keys_hi) return fail(h, KDF_ERR_INVALID, "kdf_add_pairs_multi_dev: wide keys need the hi words");
+    std::vector<const uint64_t *> lo(nseg), hi(nseg, nullptr);
+    std::vector<const uint32_t *> cnt(nseg);
+    for (uint32_t s = 0; s < nseg; ++s) {
+        lo[s] = (const uint64_t *)d_keys_lo[s]; cnt[s] = (const uint32_t *)d_counts[s];
+        if (h->kw == 2) hi[s] = (const uint64_t *)d_keys_hi[s];
+        if (n[s] && (!lo[s] || (h->kw == 2 && !hi[s]))) return fail(h, KDF_ERR_INVALID, "kdf_add_pairs_multi_dev: segment %u has NULL keys", s);
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    return add_pairs_multi(h, nseg, lo.data(), hi.data(), cnt.data(), n);
 }
 
 int kdf_add_pairs_dev(kdf_engine *h, const void *d_keys_lo, const void *d_keys_hi, const void *d_counts, uint64_t n) {
@@ -1797,49 +1886,31 @@ int kdf_query(kdf_engine *h, const uint64_t *keys_lo, const uint64_t *keys_hi, u
 }
 
 static int export_pass(kdf_engine *h, uint32_t min_count, bool write, uint64_t *olo, uint64_t *ohi,
-                       uint32_t *ocnt, uint64_t out_cap, uint64_t *n_out, uint32_t parts = 0, uint64_t *part_vals = nullptr) {
+                       uint32_t *ocnt, uint64_t out_cap, uint64_t *n_out) {
     { int rc0 = materialize(h); if (rc0) return rc0; }
     HIPCHK(h, hipMemsetAsync(h->ctl->tally, 0, sizeof(h->ctl->tally) + 8, h->stream));   // tally[] + cursor
-    std::vector<unsigned long long> stage;
-    if (parts && write) {                                   // preload the per-part cursors with the part offsets
-        stage.assign(KDF_SHARDS * 16, 0ull);
-        for (uint32_t p = 0; p < parts; ++p) stage[p * 16] = part_vals[p];
-        HIPCHK(h, hipMemcpyAsync(h->ctl->tally, stage.data(), sizeof(h->ctl->tally), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));         // `stage` is pageable
-    }
     const uint64_t waves = (h->cap + KDF_EXPORT_ROWS * 64 - 1) / (KDF_EXPORT_ROWS * 64);
     const unsigned blocks = (unsigned)((waves + 3) / 4);
-    if (write && !parts) {                                  // one read of the table (any min_count: occupancy is tested on the key)
+    if (write) {                                            // one read of the table (any min_count: occupancy is tested on the key)
         const unsigned rows = h->kw == 1 ? KDF_EXPORT1_ROWS : KDF_EXPORT1_ROWS / 2;
         const uint64_t w1 = (h->cap + rows * 64 - 1) / (rows * 64);
         const unsigned wpb = KDF_EXPORT1_THREADS / 64;
         if (h->kw == 1) hipLaunchKernelGGL(kdf_export1_kernel<1>, dim3((unsigned)((w1 + wpb - 1) / wpb)), dim3(KDF_EXPORT1_THREADS), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap);
         else hipLaunchKernelGGL(kdf_export1_kernel<2>, dim3((unsigned)((w1 + wpb - 1) / wpb)), dim3(KDF_EXPORT1_THREADS), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap);
     } else if (h->kw == 1) {
-        if (write) hipLaunchKernelGGL((kdf_export_kernel<1, true>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap, parts);
-        else hipLaunchKernelGGL((kdf_export_kernel<1, false>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap, parts);
+        hipLaunchKernelGGL((kdf_export_kernel<1, false>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap);
     } else {
-        if (write) hipLaunchKernelGGL((kdf_export_kernel<2, true>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap, parts);
-        else hipLaunchKernelGGL((kdf_export_kernel<2, false>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap, parts);
+        hipLaunchKernelGGL((kdf_export_kernel<2, false>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap);
     }
     if (h->t.sk && h->t.ovf_lo && h->ovf_used_ub) {         // the overflow array is part of the table
         KdfTable ov{};
         ov.lo = h->t.ovf_lo; ov.cnt = h->t.ovf_cnt; ov.log2cap = h->t.ovf_log2cap; ov.bucket_bits = ov.log2cap;
         const uint64_t ow = ((1ull << ov.log2cap) + KDF_EXPORT_ROWS * 64 - 1) / (KDF_EXPORT_ROWS * 64);
         const unsigned ob = (unsigned)((ow + 3) / 4);
-        if (write) hipLaunchKernelGGL((kdf_export_kernel<1, true>), dim3(ob), dim3(256), 0, h->stream, ov, min_count, h->ctl, olo, ohi, ocnt, out_cap, 0u);   // (small array: the two-phase kernel)
-        else hipLaunchKernelGGL((kdf_export_kernel<1, false>), dim3(ob), dim3(256), 0, h->stream, ov, min_count, h->ctl, olo, ohi, ocnt, out_cap, 0u);
+        if (write) hipLaunchKernelGGL((kdf_export_kernel<1, true>), dim3(ob), dim3(256), 0, h->stream, ov, min_count, h->ctl, olo, ohi, ocnt, out_cap);   // (small array: the two-phase kernel)
+        else hipLaunchKernelGGL((kdf_export_kernel<1, false>), dim3(ob), dim3(256), 0, h->stream, ov, min_count, h->ctl, olo, ohi, ocnt, out_cap);
     }
     HIPCHK(h, hipGetLastError());
-    if (parts) {                                            // per-part tallies (count pass) / end cursors (write pass)
-        stage.assign(KDF_SHARDS * 16, 0ull);
-        HIPCHK(h, hipMemcpyAsync(stage.data(), h->ctl->tally, sizeof(h->ctl->tally), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        uint64_t tot = 0;
-        for (uint32_t p = 0; p < parts; ++p) { if (!write) { part_vals[p] = stage[p * 16]; tot += stage[p * 16]; } else tot = stage[p * 16]; }
-        *n_out = tot;                                       // write pass: end of the last part = total
-        return KDF_OK;
-    }
     uint64_t cursor = 0;
     int rc = ctl_sync(h, nullptr, &cursor);
     if (rc) return rc;
@@ -1847,6 +1918,7 @@ static int export_pass(kdf_engine *h, uint32_t min_count, bool write, uint64_t *
     return KDF_OK;
 }
 
+// The sender's half of the multi-GPU merge (kdf_merge.h): the table in hash order, one contiguous range per owner.
 int kdf_export_parts_dev(kdf_engine *h, uint32_t min_count, uint32_t parts, void *d_keys_lo_out, void *d_keys_hi_out,
                          void *d_counts_out, uint64_t cap, uint64_t *part_counts_out, uint64_t *n_out) {
     if (!h || !n_out || !part_counts_out) return fail(h, KDF_ERR_INVALID, "kdf_export_parts_dev: NULL pointer");
@@ -1854,24 +1926,44 @@ int kdf_export_parts_dev(kdf_engine *h, uint32_t min_count, uint32_t parts, void
     HIPCHK(h, hipSetDevice(h->device));
     { int rc0 = materialize(h); if (rc0) return rc0; }
     if (h->t.sk) return fail(h, KDF_ERR_STATE, "kdf_export_parts_dev: the table is minimizer-bucketed (owners are not slot ranges)");
-    if (h->t.log2cap < 16 + std::max<uint32_t>(11, h->t.bucket_bits))
-        return fail(h, KDF_ERR_STATE, "kdf_export_parts_dev: table of 2^%u slots is too small for an owner-ordered dump (needs 2^%u)",
-                    h->t.log2cap, 16 + std::max<uint32_t>(11, h->t.bucket_bits));
-    uint64_t n = 0;
-    int rc = export_pass(h, min_count, false, nullptr, nullptr, nullptr, 0, &n, parts, part_counts_out);
+    if (h->t.hshift) return fail(h, KDF_ERR_STATE, "kdf_export_parts_dev: an owner table (hash_shift) is not dumped by owner again");
+    if (h->t.log2cap < 28)                                  // an owner boundary (a 16-bit hash prefix) must be a block boundary
+        return fail(h, KDF_ERR_STATE, "kdf_export_parts_dev: table of 2^%u slots is too small for an owner-ordered dump (needs 2^28)", h->t.log2cap);
+    const bool have_out = d_keys_lo_out && (h->kw == 1 || d_keys_hi_out);
+    const uint64_t nblk = h->cap / KM_BLOCK_SLOTS;
+    // scratch: blk_off u64[nblk + 1] | part_first u64[KDF_SHARDS] | part_off u64[KDF_SHARDS + 1] | blk_cnt u32[nblk]
+    const size_t off_words = nblk + 1 + KDF_SHARDS + KDF_SHARDS + 1;
+    int rc = merge_reserve(h, off_words * 8 + nblk * 4);
     if (rc) return rc;
+    unsigned long long *blk_off = (unsigned long long *)h->merge_buf;
+    uint64_t *part_first = (uint64_t *)(blk_off + nblk + 1);
+    unsigned long long *part_off = (unsigned long long *)(part_first + KDF_SHARDS);
+    uint32_t *blk_cnt = (uint32_t *)(part_off + KDF_SHARDS + 1);
+    std::vector<uint64_t> pf(KDF_SHARDS, 0);
+    for (uint32_t p = 0; p < parts; ++p) {                  // first 16-bit hash prefix t with ((t * parts) >> 16) == p
+        const uint64_t t16 = ((uint64_t)p * 65536 + parts - 1) / parts;
+        pf[p] = (t16 << (h->t.log2cap - 16)) / KM_BLOCK_SLOTS;
+    }
+    HIPCHK(h, hipMemcpyAsync(part_first, pf.data(), KDF_SHARDS * 8, hipMemcpyHostToDevice, h->stream));
+    std::vector<unsigned long long> po(KDF_SHARDS + 1, 0);
+    by_width(h, [&](auto KWc) {
+        constexpr int KW = decltype(KWc)::value;
+        hipLaunchKernelGGL(km_count_kernel<KW>, dim3((unsigned)nblk), dim3(KM_THREADS), 0, h->stream, h->t, min_count, blk_cnt);
+        hipLaunchKernelGGL(km_scan_kernel, dim3(1), dim3(1024), 0, h->stream, blk_cnt, blk_off, nblk, part_first, parts, part_off);
+        if (have_out)
+            hipLaunchKernelGGL(km_write_kernel<KW>, dim3((unsigned)nblk), dim3(KM_THREADS), 0, h->stream, h->t, min_count, blk_off,
+                               (uint64_t *)d_keys_lo_out, h->kw == 2 ? (uint64_t *)d_keys_hi_out : nullptr, (uint32_t *)d_counts_out, cap);
+        return 0;
+    });
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(po.data(), part_off, (parts + 1) * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));             // the one synchronisation of the dump (pf / po are pageable)
+    const uint64_t n = po[parts];
+    for (uint32_t p = 0; p < parts; ++p) part_counts_out[p] = po[p + 1] - po[p];
     *n_out = n;
     if (n == 0) return KDF_OK;
     if (n > cap) return fail(h, KDF_ERR_INVALID, "kdf_export_parts_dev: %llu entries, room for %llu", (unsigned long long)n, (unsigned long long)cap);
-    if (!d_keys_lo_out || (h->kw == 2 && !d_keys_hi_out)) return fail(h, KDF_ERR_INVALID, "kdf_export_parts_dev: NULL key output");
-    std::vector<uint64_t> offs(parts);
-    uint64_t acc = 0;
-    for (uint32_t p = 0; p < parts; ++p) { offs[p] = acc; acc += part_counts_out[p]; }
-    uint64_t n2 = 0;
-    rc = export_pass(h, min_count, true, (uint64_t *)d_keys_lo_out, h->kw == 2 ? (uint64_t *)d_keys_hi_out : nullptr,
-                     (uint32_t *)d_counts_out, n, &n2, parts, offs.data());
-    if (rc) return rc;
-    if (n2 != n) return fail(h, KDF_ERR_STATE, "kdf_export_parts_dev: table changed between passes");
+    if (!have_out) return fail(h, KDF_ERR_INVALID, "kdf_export_parts_dev: NULL key output");
     return KDF_OK;
 }
 
@@ -2095,6 +2187,16 @@ int kdf_set_option(kdf_engine *h, const char *name, int64_t value) {
     }
     else if (n == "binned_filtered_min_log2cap") h->opt_binned_filtered_min_log2cap = (uint32_t)value;
     else if (n == "force_path") h->opt_force_path = (int)value;
+    else if (n == "hash_shift") {
+        if (value > 8) return fail(h, KDF_ERR_INVALID, "hash_shift must be 0..8");
+        if (h->t.sk) return fail(h, KDF_ERR_STATE, "hash_shift: the table is minimizer-bucketed");
+        if ((uint32_t)value != h->opt_hash_shift) {
+            int rc = ctl_sync(h, nullptr);
+            if (rc) return rc;
+            if (h->distinct) return fail(h, KDF_ERR_STATE, "hash_shift can only change on an empty table (kdf_clear first)");
+        }
+        h->opt_hash_shift = (uint32_t)value; h->t.hshift = (uint32_t)value;
+    }
     else if (n == "sk_min_k") h->opt_sk_min_k = (uint32_t)value;
     else if (n == "sk_balance") h->opt_sk_balance = (int)value;
     else if (n == "sk_auto") h->opt_sk_auto = (int)value;
@@ -2120,6 +2222,8 @@ int kdf_get_stat(kdf_engine *h, const char *name, int64_t *value) {
     else if (n == "binned_cells") *value = (h->opt_binned_cells && !h->cells_overflowed) ? h->opt_binned_cells : 0;
     else if (n == "layout") *value = h->t.sk ? (h->t.sk_assign ? 2 : 1) : 0;
     else if (n == "last_count_path") *value = h->last_path;
+    else if (n == "last_merge_path") *value = h->last_merge_path;
+    else if (n == "hash_shift") *value = h->opt_hash_shift;
     else if (n == "ovf_log2cap") *value = h->t.ovf_lo ? (int64_t)h->t.ovf_log2cap : 0;
     else if (n == "log2cap") *value = h->t.log2cap;
     else if (n == "bucket_bits") *value = h->t.bucket_bits;

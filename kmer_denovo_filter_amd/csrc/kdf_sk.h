@@ -51,6 +51,9 @@
 #ifndef SK_BUCKET_BITS
 #define SK_BUCKET_BITS 11                  // slots per bucket of an SK-layout table (2^11: three 256-thread bucket workgroups per CU)
 #endif
+#ifndef SK_C_LA
+#define SK_C_LA      2                     // slots of an item's probe sequence read up front
+#endif
 #ifndef SK_C_WQ
 #define SK_C_WQ      96                    // per wave: keys whose probe goes past the two slots read up front
 #endif
@@ -692,7 +695,7 @@ __global__ __launch_bounds__(SK_C_THREADS) void sk_bucket_kernel(SkPlan plan, Sk
                 uint64_t *wqk = qk + (tid >> 6) * SK_C_WQ; uint32_t *wqm = qm + (tid >> 6) * SK_C_WQ; uint16_t *wqs = qs + (tid >> 6) * SK_C_WQ;
                 uint32_t wq_n = 0;
                 for (uint32_t i0 = tid & ~63u; i0 < nit; i0 += 4 * CT) {       // wave-uniform trip count
-                    uint64_t key[4], c0[4], c1[4]; uint32_t mult[4], sl0[4]; bool td[4];
+                    uint64_t key[4], c[4][SK_C_LA]; uint32_t mult[4], sl0[4]; bool td[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const uint32_t i = i0 + (tid & 63u) + u * CT;
@@ -700,18 +703,22 @@ __global__ __launch_bounds__(SK_C_THREADS) void sk_bucket_kernel(SkPlan plan, Sk
                         td[u] = it != 0xFFFFu;
                         key[u] = 0; mult[u] = 0; sl0[u] = 0;
                         if (td[u]) td[u] = item_key(it, key[u], mult[u], sl0[u]);
-                        c0[u] = tlo[sl0[u]]; c1[u] = tlo[(sl0[u] + 1) & bmask];
+#pragma unroll
+                        for (int a = 0; a < SK_C_LA; ++a) c[u][a] = tlo[(sl0[u] + a) & bmask];
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(c0[u]), "+v"(c1[u]));    // all eight reads issued before the first key is resolved
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int a = 0; a < SK_C_LA; ++a) asm volatile("" : "+v"(c[u][a]));    // all reads issued before the first key is resolved
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         if (!__any(td[u])) continue;
-                        uint32_t r = 2; bool hit = false;
-                        if (c1[u] == key[u] || c1[u] == KDF_EMPTY) { r = 1; hit = c1[u] == key[u]; }
-                        if (c0[u] == key[u] || c0[u] == KDF_EMPTY) { r = 0; hit = c0[u] == key[u]; }
+                        uint32_t r = SK_C_LA; bool hit = false;
+#pragma unroll
+                        for (int a = SK_C_LA - 1; a >= 0; --a)
+                            if (c[u][a] == key[u] || c[u][a] == KDF_EMPTY) { r = (uint32_t)a; hit = c[u][a] == key[u]; }
                         uint32_t sl = (sl0[u] + r) & bmask;
-                        bool more = td[u] && r == 2;
+                        bool more = td[u] && r == SK_C_LA;
                         hit = hit && td[u];
                         if (td[u]) nwin += mult[u];
                         if (td[u] && !more && !hit) {                            // read as empty: the CAS tells

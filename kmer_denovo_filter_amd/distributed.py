@@ -70,6 +70,15 @@ class TableOps:
     def count_ge(self, min_count: int) -> int: raise NotImplementedError
     def stats(self) -> Tuple[int, int, int]: raise NotImplementedError
 
+    def add_pairs_segments(self, segments):
+        """Sum the segments [(lo, hi, cnt), ...] received from the source ranks (a table that can merge them
+        in one pass overrides this)."""
+        for lo, hi, cnt in segments:
+            self.add_pairs(lo, hi, cnt)
+
+    def prepare_owner(self, world: int):
+        """Called once on the table that will hold the keys this rank OWNS out of ``world`` ranks."""
+
 
 class EngineOps(TableOps):
     """TableOps over a KmerEngine; tensors are int64 / int32 views of the
@@ -109,7 +118,7 @@ class EngineOps(TableOps):
     def export_pairs_by_owner(self, world: int):
         """(lo, hi, cnt, per-owner counts) already grouped by owner rank, or None when
         the table is too small for the engine's owner-ordered dump."""
-        if self.e.get_stat("layout") != 0 or self.e.get_stat("log2cap") < 16 + max(11, self.e.get_stat("bucket_bits")) or world > 64:
+        if self.e.get_stat("layout") != 0 or self.e.get_stat("log2cap") < 28 or world > 64 or self.e.get_stat("hash_shift"):
             return None
         _, distinct, _ = self.e.stats()
         lo = torch.empty(distinct, dtype=torch.int64, device=self.device)
@@ -129,6 +138,25 @@ class EngineOps(TableOps):
         self._sync()
         self.e.add_pairs_dev(lo.data_ptr(), hi.data_ptr() if hi is not None else None, cnt.data_ptr(), lo.numel())
         self.e.synchronize()
+
+    def add_pairs_segments(self, segments):
+        """All source ranks' segments in ONE engine call: when they arrive in hash order (the engine's
+        owner-ordered dump) every table bucket is merged in LDS and written once (csrc/kdf_merge.h)."""
+        segs = [(lo.contiguous(), hi.contiguous() if hi is not None else None, cnt.contiguous())
+                for lo, hi, cnt in segments if lo.numel()]
+        if not segs:
+            return
+        self._sync()
+        self.e.add_pairs_multi_dev([(lo.data_ptr(), hi.data_ptr() if hi is not None else None, cnt.data_ptr(), lo.numel())
+                                    for lo, hi, cnt in segs])
+        self.e.synchronize()
+
+    def prepare_owner(self, world: int):
+        """An owner only ever sees keys whose top hash bits name it: its table drops floor(log2(world)) of them
+        from the home slot (engine option ``hash_shift``), so the whole table is used and the senders' hash
+        order is the table's bucket order.  (world not a power of two: the owner's keys cover
+        2^floor(log2 world) / world of the table; ask for that much more capacity.)"""
+        self.e.set_option("hash_shift", max(0, int(world).bit_length() - 1))
 
     def query(self, lo, hi):
         out = torch.zeros(lo.numel(), dtype=torch.int32, device=self.device)
@@ -218,6 +246,8 @@ class OwnerPartitionedCount:
                              "(owner_ops or make_owner_ops) must be distinct from the local one")
         # with one rank the local table already is the global one
         self.owner = owner_ops if self.world > 1 else local_ops
+        if self.world > 1 and hasattr(self.owner, "prepare_owner"):
+            self.owner.prepare_owner(self.world)
         self._local_stats = (0, 0, 0)
         self.last_exchange_pairs = 0
 
@@ -268,7 +298,8 @@ class OwnerPartitionedCount:
         if self.host:
             recv = recv.to(lo.device)
         off = 0
-        for n, nb in zip(r_list, r_bytes):           # the owner sums source by source, straight from the segments
+        segments = []
+        for n, nb in zip(r_list, r_bytes):           # the owner sums straight from the received segments, all sources at once
             if n:
                 rlo = recv[off:off + 8 * n].view(torch.int64)
                 o2 = off + 8 * n
@@ -276,8 +307,13 @@ class OwnerPartitionedCount:
                 if hi is not None:
                     rhi = recv[o2:o2 + 8 * n].view(torch.int64)
                     o2 += 8 * n
-                self.owner.add_pairs(rlo, rhi, recv[o2:o2 + 4 * n].view(torch.int32))
+                segments.append((rlo, rhi, recv[o2:o2 + 4 * n].view(torch.int32)))
             off += nb
+        if hasattr(self.owner, "add_pairs_segments"):
+            self.owner.add_pairs_segments(segments)
+        else:
+            for seg in segments:
+                self.owner.add_pairs(*seg)
 
     def clear(self):
         self.local.clear()

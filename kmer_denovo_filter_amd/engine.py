@@ -153,6 +153,20 @@ class KmerEngine:
                                              c_void_p(d_counts) if d_counts else None, int(n)))
         return self
 
+    def add_pairs_multi_dev(self, segments):
+        """Sum several device-resident segments of (lo ptr, hi ptr or None, counts ptr, n) into the table in ONE call
+        (the owner's half of the multi-GPU merge, ``kdf_add_pairs_multi_dev``)."""
+        segs = [s for s in segments if s[3]]
+        if not segs:
+            return self
+        m = len(segs)
+        lo = (c_void_p * m)(*[s[0] for s in segs])
+        hi = (c_void_p * m)(*[s[1] or None for s in segs])
+        cnt = (c_void_p * m)(*[s[2] for s in segs])
+        n = (c_uint64 * m)(*[int(s[3]) for s in segs])
+        self._ck(self._lib.kdf_add_pairs_multi_dev(self._h, m, lo, hi if self.wide else None, cnt, n))
+        return self
+
     def load_filter(self, lo: np.ndarray, hi: Optional[np.ndarray] = None):
         lo = np.ascontiguousarray(lo, dtype=np.uint64)
         if self.wide:

@@ -177,6 +177,7 @@ def _two_rank_worker(rank, world, port, k, q):
                 m.count_local(shards[rank].packed, shards[rank].invalid, shards[rank].n_bases)
             assert le.get_stat("log2cap") >= 28                   # the owner-ordered dump is the path taken
             g5 = m.merge(5)                                       # ONE merge closes the job
+            assert oe.get_stat("hash_shift") == 1 and oe.get_stat("last_merge_path") == 1   # hash-ordered segments, LDS bucket merge
             got = [oe.count_ge(c) for c in (1, 2, 5)] + [g5]      # this rank's share + the global figure
             owned = oe.stats()[1]
         if rank == 0:                                            # the same job on one engine
