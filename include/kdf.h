@@ -124,6 +124,18 @@ int kdf_count_reads(kdf_engine *h, const uint64_t *packed, const uint64_t *inval
 int kdf_count_reads_dev(kdf_engine *h, const void *d_packed, const void *d_invalid,
                         uint64_t n_bases);
 
+/* Double-buffered feeding of a streamed sample (the `samtools fasta | jellyfish count` pipe,
+ * core/jellyfish_wrappers.py:166-199, as two overlapping stages): kdf_upload_reads_async copies a host batch into
+ * device staging slot 0 or 1 on a copy stream of the engine's own and returns at once when the host arrays are pinned
+ * (kdf_host_alloc; pageable arrays work too, the copy is then synchronous); kdf_count_uploaded counts the batch a
+ * slot holds (filtered != 0: count --if) on the engine's stream.  Upload batch i + 1, then count batch i: the copy
+ * runs under the count.  The host arrays of a batch may be rewritten once kdf_count_uploaded for THAT batch returned. */
+int kdf_host_alloc(uint64_t bytes, void **out);
+int kdf_host_free(void *p);
+int kdf_upload_reads_async(kdf_engine *h, int slot, const uint64_t *packed, const uint64_t *invalid,
+                           uint64_t n_bases);
+int kdf_count_uploaded(kdf_engine *h, int slot, int filtered);
+
 /* Insert-or-add explicit (key, count) pairs: key i gains counts[i] (counts ==
  * NULL adds 0, i.e. plain insertion).  Loads an on-disk index into the table
  * (`jellyfish query` mmaps the .jf; discovery/pipeline.py:286-288) and merges

@@ -35,6 +35,10 @@ SYMBOLS = [
     ("kdf_count_reads", c_int, [_P, _P, _P, c_uint64]),
     ("kdf_count_reads_dev", c_int, [_P, _P, _P, c_uint64]),
     ("kdf_add_pairs", c_int, [_P, _P, _P, _P, c_uint64]),
+    ("kdf_host_alloc", c_int, [c_uint64, POINTER(c_void_p)]),
+    ("kdf_host_free", c_int, [_P]),
+    ("kdf_upload_reads_async", c_int, [_P, c_int, _P, _P, c_uint64]),
+    ("kdf_count_uploaded", c_int, [_P, c_int, c_int]),
     ("kdf_add_pairs_dev", c_int, [_P, _P, _P, _P, c_uint64]),
     ("kdf_add_pairs_multi_dev", c_int, [_P, c_uint32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_uint64)]),
     ("kdf_load_filter", c_int, [_P, _P, _P, c_uint64]),

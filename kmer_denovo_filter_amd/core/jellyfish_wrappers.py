@@ -23,12 +23,12 @@ from .. import jf_io
 from .._native import KdfError
 from ..engine import KmerEngine
 from ..kmer_fasta import read_kmer_fasta_keys
-from ..reads import bam_reader, fasta_reader, keys_to_kmers
+from ..reads import bam_reader, fasta_reader, keys_to_kmers, stream_batches_overlapped
 
 logger = logging.getLogger(__name__)
 
 # stream positions per host->HBM batch (bounded host memory: 2 bits + 1 bit per base)
-BATCH_BASES = 1 << 27
+BATCH_BASES = 1 << 26
 
 
 def _format_elapsed(seconds):
@@ -109,15 +109,10 @@ def _stream_bam(engine, bam_path, ref_fasta, threads, filtered):
             "jellyfish count failed: CRAM input needs htslib, which the MI355X engine does not link; "
             "convert to BAM (samtools view -b) first"
         )
-    n_reads = 0
+    # decode (reader thread + its inflate workers) | H2D from pinned buffers on a copy stream | count: three stages
+    # that overlap, where the reference's pipe overlaps samtools and jellyfish
     with bam_reader(bam_path, max_bases=BATCH_BASES, max_reads=1 << 21, threads=max(1, threads)) as rd:
-        for batch in rd:
-            if filtered:
-                engine.count_filtered(batch)
-            else:
-                engine.count(batch)
-            n_reads += batch.n_reads
-    return n_reads
+        return stream_batches_overlapped(engine, rd, filtered)
 
 
 def _scan_parent_jellyfish(parent_bam, ref_fasta, kmer_fasta, kmer_size, parent_dir, threads=4,

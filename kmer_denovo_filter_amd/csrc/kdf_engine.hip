@@ -444,6 +444,11 @@ struct kdf_engine {
     bool cells_overflowed = false;                   // sticky: this engine's input is too skewed for fixed cells
     int opt_binned_pool = 0;                         // binned path: 1 = pool scatter without the histogram pass (measured SLOWER: 6.4 ms
                                                      // against A0 + A1 = 5.9 ms, the scatter sits at the 128-VGPR limit), 0 = A0 + A1 + B
+    // double-buffered feeding (kdf_upload_reads_async / kdf_count_uploaded): two device staging slots filled on a copy
+    // stream of their own, so the H2D copy of batch i + 1 runs under the count of batch i
+    void *up_buf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; size_t up_bytes[2][2] = {{0, 0}, {0, 0}};
+    uint64_t up_n[2] = {0, 0}; bool up_valid[2] = {false, false};
+    hipStream_t copy_stream = nullptr; hipEvent_t up_done[2] = {nullptr, nullptr}, use_done[2] = {nullptr, nullptr};
     void *merge_buf = nullptr; size_t merge_bytes = 0;   // kdf_merge.h: block counts / offsets of the ordered dump, bucket ranges of a merge
     uint32_t merge_flag_host = 0;
     int last_merge_path = 0;                         // 0 none yet, 1 LDS bucket merge launched, 2 plain atomic insert
@@ -1436,6 +1441,8 @@ static int count_filtered_dev(kdf_engine *h, const uint64_t *d_packed, const uin
     return KDF_OK;
 }
 
+__global__ void kdf_mask_tail_kernel(uint64_t *word, uint64_t bits) { *word |= bits; }
+
 static int upload_stream(kdf_engine *h, const uint64_t *packed, const uint64_t *invalid, uint64_t n_bases,
                          uint64_t **d_packed, uint64_t **d_invalid) {
     uint64_t pw, mw;
@@ -1508,6 +1515,12 @@ void kdf_destroy(kdf_engine *h) {
     for (int i = 0; i < 16; ++i) if (h->sk_buf[i]) (void)hipFree(h->sk_buf[i]);
     for (int i = 0; i < 8; ++i) if (h->kp_buf[i]) (void)hipFree(h->kp_buf[i]);
     if (h->merge_buf) (void)hipFree(h->merge_buf);
+    for (int sl = 0; sl < 2; ++sl) {
+        for (int j = 0; j < 2; ++j) if (h->up_buf[sl][j]) (void)hipFree(h->up_buf[sl][j]);
+        if (h->up_done[sl]) (void)hipEventDestroy(h->up_done[sl]);
+        if (h->use_done[sl]) (void)hipEventDestroy(h->use_done[sl]);
+    }
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->sieve) (void)hipFree(h->sieve);
     if (h->sk_assign) (void)hipFree(h->sk_assign);
     if (h->sk_weights) (void)hipFree(h->sk_weights);
@@ -1533,6 +1546,7 @@ int kdf_synchronize(kdf_engine *h) {
     if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->copy_stream) HIPCHK(h, hipStreamSynchronize(h->copy_stream));      // uploads still in flight read host buffers
     return KDF_OK;
 }
 
@@ -1586,6 +1600,76 @@ int kdf_count_reads(kdf_engine *h, const uint64_t *packed, const uint64_t *inval
     int rc = upload_stream(h, packed, invalid, n_bases, &dp, &dm);
     if (rc) return rc;
     return count_insert_dev(h, dp, dm, n_bases);
+}
+
+int kdf_host_alloc(uint64_t bytes, void **out) {
+    if (!out) return fail(nullptr, KDF_ERR_INVALID, "kdf_host_alloc: NULL pointer");
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 8, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, KDF_ERR_NOMEM, "kdf_host_alloc: %s", hipGetErrorString(e)); }
+    return KDF_OK;
+}
+int kdf_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+    return KDF_OK;
+}
+
+int kdf_upload_reads_async(kdf_engine *h, int slot, const uint64_t *packed, const uint64_t *invalid, uint64_t n_bases) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    if (slot < 0 || slot > 1) return fail(h, KDF_ERR_INVALID, "kdf_upload_reads_async: slot must be 0 or 1");
+    if (n_bases && (!packed || !invalid)) return fail(h, KDF_ERR_INVALID, "kdf_upload_reads_async: NULL stream");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->copy_stream) {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        for (int sl = 0; sl < 2; ++sl) {
+            HIPCHK(h, hipEventCreateWithFlags(&h->up_done[sl], hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&h->use_done[sl], hipEventDisableTiming));
+        }
+    }
+    uint64_t pw, mw;
+    kdf_stream_words(n_bases, &pw, &mw);
+    const size_t want[2] = {(size_t)pw * 8, (size_t)mw * 8};
+    for (int j = 0; j < 2; ++j) {
+        if (h->up_bytes[slot][j] >= want[j]) continue;
+        HIPCHK(h, hipStreamSynchronize(h->stream));            // (the slot's last count may still read the old buffer)
+        HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+        if (h->up_buf[slot][j]) (void)hipFree(h->up_buf[slot][j]);
+        h->up_buf[slot][j] = nullptr; h->up_bytes[slot][j] = 0;
+        const size_t sz = want[j] + want[j] / 8 + 4096;
+        HIPCHK(h, hipMalloc(&h->up_buf[slot][j], sz));
+        h->up_bytes[slot][j] = sz;
+    }
+    h->up_valid[slot] = false;
+    h->up_n[slot] = n_bases;
+    if (n_bases == 0) { h->up_valid[slot] = true; return KDF_OK; }
+    hipStream_t cs = h->copy_stream;
+    if (h->use_done[slot]) HIPCHK(h, hipStreamWaitEvent(cs, h->use_done[slot], 0));   // the count that last read this slot
+    const uint64_t pw_in = (n_bases + 31) / 32, mw_in = (n_bases + 63) / 64;
+    // the caller's arrays hold ceil(n/32) / ceil(n/64) meaningful words: pad the rest on the device
+    if (pw > pw_in) HIPCHK(h, hipMemsetAsync((uint64_t *)h->up_buf[slot][0] + pw_in, 0, (pw - pw_in) * 8, cs));
+    if (mw > mw_in) HIPCHK(h, hipMemsetAsync((uint64_t *)h->up_buf[slot][1] + mw_in, 0xFF, (mw - mw_in) * 8, cs));
+    HIPCHK(h, hipMemcpyAsync(h->up_buf[slot][0], packed, pw_in * 8, hipMemcpyHostToDevice, cs));
+    HIPCHK(h, hipMemcpyAsync(h->up_buf[slot][1], invalid, mw_in * 8, hipMemcpyHostToDevice, cs));
+    if (n_bases % 64)                                           // bits past n_bases in the last mask word must read "invalid"
+        hipLaunchKernelGGL(kdf_mask_tail_kernel, dim3(1), dim3(1), 0, cs, (uint64_t *)h->up_buf[slot][1] + (mw_in - 1), ~0ull << (n_bases % 64));
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->up_done[slot], cs));
+    h->up_valid[slot] = true;
+    return KDF_OK;
+}
+
+int kdf_count_uploaded(kdf_engine *h, int slot, int filtered) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    if (slot < 0 || slot > 1 || !h->up_valid[slot]) return fail(h, KDF_ERR_STATE, "kdf_count_uploaded: nothing was uploaded into slot %d", slot);
+    HIPCHK(h, hipSetDevice(h->device));
+    h->up_valid[slot] = false;
+    const uint64_t n = h->up_n[slot];
+    if (n == 0) return KDF_OK;
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->up_done[slot], 0));
+    const uint64_t *dp = (const uint64_t *)h->up_buf[slot][0], *dm = (const uint64_t *)h->up_buf[slot][1];
+    const int rc = filtered ? count_filtered_dev(h, dp, dm, n) : count_insert_dev(h, dp, dm, n);
+    (void)hipEventRecord(h->use_done[slot], h->stream);
+    return rc;
 }
 
 // Size, allocate and zero the membership sieve for n keys (sieve_valid says whether there is one).  Every window costs

@@ -133,6 +133,16 @@ class KmerEngine:
         self._ck(self._lib.kdf_count_reads(self._h, _vp(stream.packed), _vp(stream.invalid), stream.n_bases))
         return self
 
+    def upload_async(self, slot: int, stream: ReadStream):
+        """Copy a host batch into device staging slot 0 / 1 on the engine's copy stream (asynchronous when the
+        arrays are pinned, reads.PinnedBatches); count it later with count_uploaded(slot)."""
+        self._ck(self._lib.kdf_upload_reads_async(self._h, int(slot), _vp(stream.packed), _vp(stream.invalid), stream.n_bases))
+        return self
+
+    def count_uploaded(self, slot: int, filtered: bool = False):
+        self._ck(self._lib.kdf_count_uploaded(self._h, int(slot), 1 if filtered else 0))
+        return self
+
     def count_dev(self, d_packed: int, d_invalid: int, n_bases: int):
         """Stream resident in HBM (raw device pointers, padded per stream_words).
         The engine launches on its own stream unless set_stream() was called:

@@ -157,6 +157,32 @@ class _Reader:
     def __exit__(self, *a):
         self.close()
 
+    def _next(self, packed, invalid, so):
+        """One batch into the given arrays -> ReadStream (views of them), or None at end of file."""
+        n_reads, nb = c_int64(0), c_uint64(0)
+        rc = self._lib.kdf_reader_next(self._h, self.max_bases, self.max_reads, _vp(packed), _vp(invalid),
+                                       _vp(so), byref(n_reads), byref(nb))
+        _native.check_reader(rc, self._h)
+        n = n_reads.value
+        if n == 0:
+            return None
+        pw_used, mw_used = stream_words(nb.value)
+        return ReadStream(packed[:pw_used], invalid[:mw_used], nb.value, so[:n + 1].copy())
+
+    def next_into(self, packed: np.ndarray, invalid: np.ndarray):
+        """Sequence-only batch into caller-owned arrays (e.g. pinned ones, PinnedBatches) of stream_words(max_bases)
+        words; no per-record metadata.  None at end of file."""
+        if not self._h:
+            return None
+        pw, mw = stream_words(self.max_bases)
+        if len(packed) < pw or len(invalid) < mw:
+            raise ValueError("batch arrays are smaller than stream_words(max_bases)")
+        so = np.empty(self.max_reads + 1, np.int64)
+        st = self._next(packed, invalid, so)
+        if st is None:
+            self.close()
+        return st
+
     def __iter__(self) -> Iterator[ReadStream]:
         lib = self._lib
         pw, mw = stream_words(self.max_bases)
@@ -164,15 +190,10 @@ class _Reader:
             packed = np.empty(pw, np.uint64)           # the native reader initialises both arrays
             invalid = np.empty(mw, np.uint64)
             so = np.empty(self.max_reads + 1, np.int64)
-            n_reads, nb = c_int64(0), c_uint64(0)
-            rc = lib.kdf_reader_next(self._h, self.max_bases, self.max_reads, _vp(packed), _vp(invalid),
-                                     _vp(so), byref(n_reads), byref(nb))
-            _native.check_reader(rc, self._h)
-            n = n_reads.value
-            if n == 0:
+            st = self._next(packed, invalid, so)
+            if st is None:
                 break
-            pw_used, mw_used = stream_words(nb.value)
-            st = ReadStream(packed[:pw_used], invalid[:mw_used], nb.value, so[:n + 1].copy())
+            n = st.n_reads
             if self.want_meta:
                 f, r, p = POINTER(c_uint16)(), POINTER(c_int32)(), POINTER(c_int32)()
                 nbuf, noff = c_char_p(), POINTER(c_int64)()
@@ -216,6 +237,114 @@ class _Reader:
                 st.mapq = np.ctypeslib.as_array(mq, (n,)).copy()
             yield st
         self.close()
+
+
+class PinnedBatches:
+    """A ring of page-locked host batches (packed + invalid words for ``max_bases`` stream positions each): the H2D copy
+    of one is asynchronous, so it can run while the GPU counts the batch before it and the reader fills the next."""
+
+    def __init__(self, n: int, max_bases: int):
+        self._lib = _native.load()
+        self._ptrs = []
+        self.batches = []
+        pw, mw = stream_words(max_bases)
+        try:
+            for _ in range(n):
+                arrs = []
+                for words in (pw, mw):
+                    p = c_void_p()
+                    _native.check(self._lib.kdf_host_alloc(words * 8, byref(p)), None)
+                    self._ptrs.append(p)
+                    arrs.append(np.ctypeslib.as_array(ctypes.cast(p, POINTER(c_uint64)), (words,)))
+                self.batches.append(tuple(arrs))
+        except Exception:
+            self.close()
+            raise
+
+    def close(self):
+        self.batches = []
+        for p in self._ptrs:
+            self._lib.kdf_host_free(p)
+        self._ptrs = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+_pinned_cache = {}            # (ring, max_bases) -> PinnedBatches, kept for the life of the process: page-locking ~50 MB per
+#                               batch costs more than counting it, and the child and both parents stream one after another
+
+
+def _pinned_ring(ring: int, max_bases: int) -> PinnedBatches:
+    key = (ring, max_bases)
+    pb = _pinned_cache.get(key)
+    if pb is None or not pb.batches:
+        for old in list(_pinned_cache.values()):
+            old.close()
+        _pinned_cache.clear()
+        pb = _pinned_cache[key] = PinnedBatches(ring, max_bases)
+    return pb
+
+
+def stream_batches_overlapped(engine, reader, filtered: bool, ring: int = 3) -> int:
+    """Count every batch of ``reader`` on ``engine`` as a three-stage pipeline: a reader thread decodes batch i + 2
+    into a pinned buffer (the native reader releases the GIL), the copy stream uploads batch i + 1, the engine
+    counts batch i.  Returns the number of reads."""
+    import queue
+    import threading
+    n_reads = 0
+    pinned = _pinned_ring(ring, reader.max_bases)
+    if True:
+        free, ready = queue.Queue(), queue.Queue()
+        for i in range(ring):
+            free.put(i)
+        stop = threading.Event()
+
+        def produce():
+            try:
+                while not stop.is_set():
+                    i = free.get()
+                    if i is None:
+                        break
+                    st = reader.next_into(*pinned.batches[i])
+                    if st is None:
+                        break
+                    ready.put((i, st))
+                ready.put(None)
+            except BaseException as ex:  # noqa: BLE001 -- handed to the consumer
+                ready.put(ex)
+
+        th = threading.Thread(target=produce, name="kdf-reader", daemon=True)
+        th.start()
+        pending = None                                   # (slot, buffer) uploaded, not yet counted
+        slot = 0
+        try:
+            while True:
+                item = ready.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                i, st = item
+                engine.upload_async(slot, st)            # returns at once: the buffer is pinned
+                n_reads += st.n_reads
+                if pending is not None:
+                    engine.count_uploaded(pending[0], filtered)
+                    free.put(pending[1])                 # its copy finished before its count started
+                pending = (slot, i)
+                slot ^= 1
+            if pending is not None:
+                engine.count_uploaded(pending[0], filtered)
+                pending = None
+        finally:
+            stop.set()
+            free.put(None)
+            th.join(timeout=60)
+            engine.synchronize()                         # no copy may still read a pinned buffer the next caller will fill
+    return n_reads
 
 
 def bam_reader(path: str, flag_off: int = FLAG_OFF_SAMTOOLS_FASTA, collapse: bool = True,
