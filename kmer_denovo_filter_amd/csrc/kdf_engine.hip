@@ -406,6 +406,7 @@ __global__ void kdf_ctl_reduce_kernel(KdfCtl *ctl, unsigned long long *out3) {
 // engine
 // ===========================================================================
 
+#define KDF_MERGE_MIN_PAIRS (1u << 16)
 struct kdf_engine {
     int device = 0;
     int k = 0;
@@ -435,6 +436,7 @@ struct kdf_engine {
     uint64_t opt_binned_max_positions = 1ull << 31;  // longer streams are walked in several binned passes: a pass must add
                                                      // < 2^32 to any slot (kernel C saturates by comparing with the HBM count)
     uint32_t opt_binned_filtered_min_log2cap = 23;   // count --if goes binned from 2^23 slots (measured crossover)
+    uint64_t opt_merge_min_pairs = KDF_MERGE_MIN_PAIRS;   // below this many pairs a merge goes straight to the atomic insert (tests lower it)
     uint32_t opt_hash_shift = 0;                     // KdfTable::hshift of the tables this engine creates (owner tables)
     int opt_force_path = 0;                          // 0 auto, 1 direct, 2 binned, 3 super-k-mer (kdf_sk.h)
     uint32_t opt_sk_min_k = 20;                      // auto (option sk_auto): narrow keys from this k on take the super-k-mer path
@@ -1785,7 +1787,6 @@ static int merge_reserve(kdf_engine *h, size_t bytes) {
 // table first so the pairs fit at load <= 0.5 even if all of them are new.  Hash-layout tables take segments of any
 // order: km_bounds_kernel tests on the device whether every segment is grouped by table bucket (a dump made by
 // kdf_export_parts_dev is) and the LDS bucket merge or the atomic insert runs accordingly -- no host decision.
-#define KDF_MERGE_MIN_PAIRS (1u << 16)
 static int add_pairs_multi(kdf_engine *h, uint32_t nseg, const uint64_t *const *d_lo, const uint64_t *const *d_hi,
                            const uint32_t *const *d_cnt, const uint64_t *n) {
     uint64_t total = 0, nmax = 0;
@@ -1816,7 +1817,7 @@ static int add_pairs_multi(kdf_engine *h, uint32_t nseg, const uint64_t *const *
         }
         return KDF_OK;
     }
-    const bool lds = counts && total >= KDF_MERGE_MIN_PAIRS && nseg <= KM_MAX_SEGS && nmax < 0xFFFFFFFFull;
+    const bool lds = counts && total >= h->opt_merge_min_pairs && nseg <= KM_MAX_SEGS && nmax < 0xFFFFFFFFull;
     if (!lds) {
         if ((rc = materialize(h))) return rc;
         for (uint32_t s = 0; s < nseg; ++s) {
@@ -2271,6 +2272,7 @@ int kdf_set_option(kdf_engine *h, const char *name, int64_t value) {
     }
     else if (n == "binned_filtered_min_log2cap") h->opt_binned_filtered_min_log2cap = (uint32_t)value;
     else if (n == "force_path") h->opt_force_path = (int)value;
+    else if (n == "merge_min_pairs") h->opt_merge_min_pairs = (uint64_t)value;
     else if (n == "hash_shift") {
         if (value > 8) return fail(h, KDF_ERR_INVALID, "hash_shift must be 0..8");
         if (h->t.sk) return fail(h, KDF_ERR_STATE, "hash_shift: the table is minimizer-bucketed");

@@ -48,3 +48,126 @@ def test_random_cases_match_oracle(oracle, seed):
                 e.set_option("force_path", path); e.set_option("debug_flags", flags); e.set_option("binned_max_positions", maxpos)
                 e.count_filtered(ReadStream.from_strings(other))
                 assert np.array_equal(e.query(lo[sel], hi[sel] if k > 32 else None), ot.query(lo[sel], hi[sel])), tag + " (count --if)"
+
+
+def khash(lo, hi):
+    x = lo.copy()
+    if hi is not None:
+        x ^= (hi << np.uint64(37)) | (hi >> np.uint64(27))
+    with np.errstate(over="ignore"):
+        return (x ^ (x >> np.uint64(32))) * np.uint64(0x9E3779B97F4A7C15)
+
+
+def round2_case(O, rng, scale, tag0):
+    """One random case over the round-2 code paths (see test_random_cases_round2_paths); returns the merge path taken."""
+    import torch
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    k = int(rng.choice([16, 21, 27, 31, 32, 33, 47, 63, int(rng.integers(1, 64))]))
+    n = int(rng.integers(50, 4000)) * scale
+    genome = rng.integers(0, 4, int(rng.integers(2000, 200000)) * scale).astype(np.uint8) if rng.random() < 0.8 else None
+    reads = rand_reads(rng, n, max(1, k - 3), int(rng.integers(k + 1, 400)), n_frac=float(rng.choice([0, 0.002, 0.05])), genome=genome)
+    if rng.random() < 0.3:
+        reads += ["A" * int(rng.integers(k, 500))] * int(rng.integers(1, 60)) + ["ACGT" * 100] * int(rng.integers(0, 20))
+    wide = k > 32
+    paths = [1, 2] + ([3, 3] if 16 <= k <= 32 else [])
+    path = int(rng.choice(paths))
+    cells = int(rng.choice([0, 2])) if path == 2 else 0
+    pool = int(rng.choice([0, 1])) if path == 2 and not cells else 0
+    hshift = int(rng.choice([0, 0, 1, 3]))
+    hint = int(rng.choice([1 << 8, 1 << 12, 1 << 16, 1 << 20]))
+    maxpos = int(rng.choice([1 << 31, 4096, 65536]))
+    tag = f"{tag0} k={k} reads={len(reads)} path={path} cells={cells} pool={pool} hshift={hshift} hint={hint} maxpos={maxpos}"
+    lo, hi, cnt = O.OracleTable(k, 1 << 12).count_reads(reads).export_ge(0)
+
+    def opts(e, p=path):
+        e.set_option("force_path", p); e.set_option("binned_max_positions", maxpos)
+        e.set_option("binned_cells", cells); e.set_option("binned_pool", pool)
+
+    with KmerEngine(k, capacity_hint=hint) as e:
+        opts(e)
+        if hshift:
+            e.set_option("hash_shift", hshift)
+        half = len(reads) // 2
+        if rng.random() < 0.5:
+            e.count(ReadStream.from_strings(reads[:half])); e.count(ReadStream.from_strings(reads[half:]))
+        else:
+            e.count(ReadStream.from_strings(reads))
+        glo, ghi, gcnt = e.export_ge(0)
+        assert np.array_equal(glo, lo) and np.array_equal(ghi, hi) and np.array_equal(gcnt, cnt), tag
+        thr = int(rng.integers(1, 6))
+        assert e.count_ge(thr) == int((cnt >= thr).sum()), tag
+        if len(lo):
+            sel = rng.choice(len(lo), size=min(len(lo), 500), replace=False)
+            assert np.array_equal(e.query(lo[sel], hi[sel] if wide else None), cnt[sel]), tag
+
+    # ---- the merge: the reads in 2-4 parts, each counted by its own engine, all dumps summed into one owner table
+    m = int(rng.integers(2, 5))
+    cut = sorted(rng.integers(0, len(reads) + 1, m - 1).tolist())
+    parts = [reads[a:b] for a, b in zip([0] + cut, cut + [len(reads)])]
+    own_shift = int(rng.choice([0, 1, 2, 3]))
+    ordered = rng.random() < 0.7
+    dev = torch.device("cuda:0")
+    segs, keep = [], []
+    for pr in parts:
+        if not pr:
+            continue
+        with KmerEngine(k, capacity_hint=hint) as e:
+            opts(e, int(rng.choice(paths)))
+            e.count(ReadStream.from_strings(pr))
+            plo, phi, pcnt = e.export_ge(0)
+        if ordered and len(plo):                             # what kdf_export_parts_dev guarantees: ascending hash order
+            with np.errstate(over="ignore"):
+                h = khash(plo, phi if wide else None) << np.uint64(own_shift)
+            o = np.argsort(h, kind="stable")
+            plo, phi, pcnt = plo[o], phi[o], pcnt[o]
+        tl = torch.from_numpy(plo.view(np.int64).copy()).to(dev)
+        th = torch.from_numpy(phi.view(np.int64).copy()).to(dev) if wide else None
+        tc = torch.from_numpy(pcnt.view(np.int32).copy()).to(dev)
+        keep.append((tl, th, tc))
+        segs.append((tl.data_ptr(), th.data_ptr() if wide else None, tc.data_ptr(), len(plo)))
+    torch.cuda.synchronize()
+    with KmerEngine(k, capacity_hint=int(rng.choice([1 << 8, 1 << 16]))) as own:
+        own.set_option("hash_shift", own_shift)
+        own.set_option("merge_min_pairs", int(rng.choice([1, 1, 1 << 16])))
+        pre = rng.random() < 0.3 and len(parts[0]) > 0      # a live table: the first part is counted in directly, not merged
+        if pre:
+            own.set_option("force_path", 1)
+            own.count(ReadStream.from_strings(parts[0]))
+            segs_m = segs[1:]
+        else:
+            if rng.random() < 0.5:
+                own.clear()                                  # deferred clear: the merge writes every bucket
+            segs_m = segs
+        own.add_pairs_multi_dev(segs_m)
+        own.synchronize()
+        mp = own.get_stat("last_merge_path")
+        glo, ghi, gcnt = own.export_ge(0)
+        assert np.array_equal(glo, lo) and np.array_equal(ghi, hi) and np.array_equal(gcnt, cnt), tag + f" merge m={m} own_shift={own_shift} ordered={ordered} pre={pre} path={mp}"
+
+    # ---- count --if through the sieve / binned / direct
+    if len(lo) > 4:
+        sel = np.sort(rng.choice(len(lo), size=max(1, len(lo) // int(rng.integers(2, 6))), replace=False))
+        other = rand_reads(rng, int(rng.integers(50, 2000)) * scale, max(1, k - 3), 300, genome=genome) + reads[: len(reads) // 3]
+        ot = O.OracleTable(k, 1 << 12).load_filter(lo[sel], hi[sel]).count_reads_filtered(other)
+        fp = int(rng.choice([0, 1, 2, 4, 4])); sb = int(rng.choice([0, 8, 16, 32]))
+        with KmerEngine(k, capacity_hint=hint) as e:
+            e.set_option("sieve_bits", sb)
+            e.load_filter(lo[sel], hi[sel] if wide else None)
+            e.set_option("force_path", fp); e.set_option("binned_max_positions", maxpos)
+            e.count_filtered(ReadStream.from_strings(other))
+            assert np.array_equal(e.query(lo[sel], hi[sel] if wide else None), ot.query(lo[sel], hi[sel])), tag + f" filtered fp={fp} sb={sb}"
+            assert e.stats()[2] == O.count_windows(other, k), tag + " filtered windows"
+    return mp
+
+
+@pytest.mark.parametrize("seed", [404, 505])
+def test_random_cases_round2_paths(oracle, seed):
+    """The round-2 paths (scratch/fuzz_round2.py ran 5 849 such cases on the GPU box without a difference): super-k-mer
+    pipeline, cell / pool scatter, owner tables (hash_shift), the multi-segment merge in hash order (LDS buckets) and out
+    of order (atomic fallback), into fresh, cleared and live tables, and count --if through the sieve at every width."""
+    rng = np.random.default_rng(seed)
+    taken = set()
+    for it in range(40):
+        taken.add(round2_case(oracle, rng, 1, f"seed {seed} case {it}"))
+    assert {1, 2} <= taken                                  # both merge kernels were exercised
+
