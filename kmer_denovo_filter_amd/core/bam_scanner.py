@@ -67,15 +67,18 @@ def _init_scan_worker(proband_data, kmer_size, min_distinct_kmers_per_read=1, de
         _worker_engine = None
     try:
         if isinstance(proband_data, str) and proband_data.endswith(".jf"):
-            k, lo, hi, cnt = jf_io.read_index(proband_data, expect_k=kmer_size)
+            eng = KmerEngine(kmer_size, capacity_hint=max(jf_io.index_records(proband_data), 1), device=device)
+            jf_io.load_index_into(eng, proband_data, expect_k=kmer_size)
+            lo = None
         elif isinstance(proband_data, str):
             lo, hi = read_kmer_fasta_keys(proband_data, kmer_size)
             cnt = np.ones(len(lo), np.uint32)
         else:
             lo, hi = kmers_to_keys(list(proband_data), kmer_size)
             cnt = np.ones(len(lo), np.uint32)
-        eng = KmerEngine(kmer_size, capacity_hint=max(len(lo), 1), device=device)
-        eng.add_pairs(lo, hi, cnt)
+        if lo is not None:
+            eng = KmerEngine(kmer_size, capacity_hint=max(len(lo), 1), device=device)
+            eng.add_pairs(lo, hi, cnt)
     except (KdfError, ValueError, OSError) as e:
         raise RuntimeError(f"jellyfish query failed: {e}") from e
     _worker_engine = eng

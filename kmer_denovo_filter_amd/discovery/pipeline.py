@@ -112,14 +112,14 @@ def _subtract_reference_kmers(ref_jf, child_candidates_fa, tmpdir):
     input FASTA.  Returns (child_non_ref_fa, n_non_ref)."""
     child_non_ref_fa = os.path.join(tmpdir, "child_non_ref_kmers.fa")
     try:
-        k, rlo, rhi, rcnt = jf_io.read_index(ref_jf)
+        k = _index_k(ref_jf)
         dev = devkeys.lookup(child_candidates_fa, k)             # the candidates are still in HBM when Module 1 ran here
         if dev is None:
             lo, hi = read_kmer_fasta_keys(child_candidates_fa, k)
             dev = devkeys.from_host(lo, hi, k > 32) if len(lo) else None
         if dev is not None and dev[0].numel():
-            with KmerEngine(k, capacity_hint=max(len(rlo), 1)) as eng:
-                eng.add_pairs(rlo, rhi, rcnt)
+            with KmerEngine(k, capacity_hint=max(jf_io.index_records(ref_jf), 1)) as eng:
+                jf_io.load_index_into(eng, ref_jf)               # memory-mapped, block by block (a human index is 30 GB)
                 keep = devkeys.query(eng, dev[0], dev[1], eng.device) == 0
             dlo, dhi = dev[0][keep].contiguous(), (dev[1][keep].contiguous() if dev[1] is not None else None)
             lo, hi = devkeys.to_host(dlo, dhi)
@@ -165,9 +165,8 @@ def _count_parent_jellyfish(parent_bam, ref_fasta, kmer_fasta, kmer_size, parent
 def _query_index(jf_path, lo, hi, k, what):
     """``jellyfish query jf -s kmers.fa``: counts in input order."""
     try:
-        _, ilo, ihi, icnt = jf_io.read_index(jf_path, expect_k=k)
-        with KmerEngine(k, capacity_hint=max(len(ilo), 1)) as eng:
-            eng.add_pairs(ilo, ihi, icnt)
+        with KmerEngine(k, capacity_hint=max(jf_io.index_records(jf_path), 1)) as eng:
+            jf_io.load_index_into(eng, jf_path, expect_k=k)
             return eng.query(lo, hi)
     except (KdfError, ValueError, OSError) as e:
         raise RuntimeError(f"jellyfish query ({what}) failed: {e}") from e

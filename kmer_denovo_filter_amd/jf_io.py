@@ -37,8 +37,7 @@ def read_header(path: str) -> Tuple[dict, int]:
     return header, 9 + hlen
 
 
-def read_index(path: str, expect_k: Optional[int] = None):
-    """-> (k, lo, hi, counts) ; hi is all zero for k <= 32.  Counts saturate at 2^32-1."""
+def _index_layout(path: str, expect_k: Optional[int]):
     header, off = read_header(path)
     fmt = header.get("format")
     if fmt not in (JF_FORMAT, KDF_FORMAT):
@@ -55,18 +54,80 @@ def read_index(path: str, expect_k: Optional[int] = None):
         raise ValueError(f"{path}: k={k} is beyond the engine's key width")
     kb, cb = (key_len + 7) // 8, int(header["counter_len"])
     rec = np.dtype([("k", "u1", (kb,)), ("c", "u1", (cb,))])
-    size = os.path.getsize(path) - off
-    n = size // rec.itemsize
-    data = np.fromfile(path, dtype=rec, count=n, offset=off)
-    kbytes = np.zeros((n, 16), dtype=np.uint8)
-    kbytes[:, :kb] = data["k"]
-    lo = kbytes[:, :8].copy().view("<u8").reshape(n)
-    hi = kbytes[:, 8:].copy().view("<u8").reshape(n)
-    cbytes = np.zeros((n, 8), dtype=np.uint8)
-    cbytes[:, :min(cb, 8)] = data["c"][:, :8]
-    c64 = cbytes.view("<u8").reshape(n)
-    counts = np.minimum(c64, np.uint64(0xFFFFFFFF)).astype(np.uint32)
-    return k, lo, hi, counts
+    n = (os.path.getsize(path) - off) // rec.itemsize
+    return k, kb, cb, rec, off, n
+
+
+def index_records(path: str) -> int:
+    """Number of records of an index (from the file size; nothing is read)."""
+    return _index_layout(path, None)[5]
+
+
+def _decode(data, kb: int, cb: int):
+    """One block of records -> (lo, hi or None, counts uint32).  Little-endian byte strings of any length up to 16 / 8
+    bytes; the usual widths (8-byte keys, 4-byte counters) are plain views of one contiguous copy per field."""
+    n = len(data)
+    kraw = np.ascontiguousarray(data["k"])
+    if kb == 8:
+        lo, hi = kraw.view("<u8").reshape(n), None
+    else:
+        kbytes = np.zeros((n, 16), dtype=np.uint8)
+        kbytes[:, :kb] = kraw
+        lo = np.ascontiguousarray(kbytes[:, :8]).view("<u8").reshape(n)
+        hi = np.ascontiguousarray(kbytes[:, 8:]).view("<u8").reshape(n) if kb > 8 else None
+    craw = np.ascontiguousarray(data["c"])
+    if cb == 4:
+        counts = craw.view("<u4").reshape(n)
+    else:
+        cbytes = np.zeros((n, 8), dtype=np.uint8)
+        cbytes[:, :min(cb, 8)] = craw[:, :8]
+        c64 = cbytes.view("<u8").reshape(n)
+        if cb > 8:
+            c64 = np.where(craw[:, 8:].any(axis=1), np.uint64(0xFFFFFFFFFFFFFFFF), c64)
+        counts = np.minimum(c64, np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    return lo, hi, counts
+
+
+def iter_index(path: str, expect_k: Optional[int] = None, chunk_records: int = 1 << 24):
+    """Yield (k, lo, hi or None, counts) blocks of at most ``chunk_records`` records.  The file is memory-mapped and
+    decoded block by block, so a whole-genome index (2.5e9 records, 30 GB on disk) needs ~0.5 GB of host memory at a
+    time where `read_index` would need every record decoded at once (Jellyfish itself mmaps the file,
+    reference discovery/pipeline.py:286-288)."""
+    k, kb, cb, rec, off, n = _index_layout(path, expect_k)
+    if n == 0:
+        return
+    mm = np.memmap(path, dtype=rec, mode="r", offset=off, shape=(n,))
+    try:
+        for a in range(0, n, chunk_records):
+            lo, hi, counts = _decode(mm[a:a + chunk_records], kb, cb)
+            yield k, lo, hi, counts
+    finally:
+        del mm
+
+
+def load_index_into(engine, path: str, expect_k: Optional[int] = None, chunk_records: int = 1 << 24) -> int:
+    """Stream an index into ``engine``'s table (`jellyfish query`'s view of the .jf): the table is sized once for the
+    record count, then the blocks are added one by one.  Returns the number of records."""
+    k, _, _, _, _, n = _index_layout(path, expect_k)
+    if k != engine.k:
+        raise ValueError(f"{path}: index has k={k}, the engine counts k={engine.k}")
+    if n:
+        engine.reserve(n)
+    for _, lo, hi, counts in iter_index(path, expect_k, chunk_records):
+        engine.add_pairs(lo, hi, counts)
+    return n
+
+
+def read_index(path: str, expect_k: Optional[int] = None):
+    """-> (k, lo, hi, counts) ; hi is all zero for k <= 32.  Counts saturate at 2^32-1.  Whole file in memory:
+    callers that only feed an engine use `load_index_into`."""
+    k = _index_layout(path, expect_k)[0]
+    los, his, cnts = [], [], []
+    for _, lo, hi, counts in iter_index(path, expect_k):
+        los.append(lo); his.append(hi if hi is not None else np.zeros(len(lo), np.uint64)); cnts.append(counts)
+    if not los:
+        return k, np.zeros(0, np.uint64), np.zeros(0, np.uint64), np.zeros(0, np.uint32)
+    return k, np.concatenate(los), np.concatenate(his), np.concatenate(cnts)
 
 
 def write_index(path: str, k: int, lo: np.ndarray, hi: Optional[np.ndarray], counts: np.ndarray,

@@ -189,9 +189,9 @@ class JellyfishKmerQuery:
     def _ensure_engine(self) -> KmerEngine:
         if self._engine is None:
             try:
-                k, lo, hi, cnt = jf_io.read_index(self.jf_path)
-                eng = KmerEngine(k, capacity_hint=max(len(lo), 1), device=self._device)
-                eng.add_pairs(lo, hi, cnt)
+                k = int(jf_io.read_header(self.jf_path)[0]["key_len"]) // 2
+                eng = KmerEngine(k, capacity_hint=max(jf_io.index_records(self.jf_path), 1), device=self._device)
+                jf_io.load_index_into(eng, self.jf_path)
             except (KdfError, ValueError, OSError) as e:
                 raise RuntimeError(f"jellyfish query failed: {e}") from e
             self._engine, self.kmer_size = eng, k

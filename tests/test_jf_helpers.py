@@ -91,3 +91,33 @@ def test_merge_jf_files_sums_the_chunks(tmp_path, oracle):
     assert kk == k and dict(zip(lo.tolist(), cnt.tolist())) == exp and not hi.any()
     assert np.all(lo[1:] > lo[:-1])                                           # the on-disk index is sorted
     assert [f for f in files if os.path.exists(f)] == []                      # the chunks are gone
+
+
+def test_index_is_streamed_block_by_block(tmp_path, oracle):
+    """`iter_index` (memory-mapped blocks) gives what the oracle's reader of the real Jellyfish fixture gives, for any
+    block size; unusual key / counter widths go through the general decoder; `index_records` never reads the body."""
+    import os
+    from kmer_denovo_filter_amd import jf_io
+    path = os.path.join(os.path.dirname(__file__), "golden", "giab", "mini_ref.fa.k31.jf")
+    hdr, keys, counts = oracle.read_jf_binary_sorted(path)
+    assert jf_io.index_records(path) == len(keys) == 45275
+    for chunk in (1000, 45275, 1 << 20):
+        los, cnts = [], []
+        for k, lo, hi, c in jf_io.iter_index(path, expect_k=31, chunk_records=chunk):
+            assert k == 31 and hi is None and len(lo) <= chunk
+            los.append(lo); cnts.append(c)
+        np.testing.assert_array_equal(np.concatenate(los), np.asarray(keys, dtype=np.uint64))
+        np.testing.assert_array_equal(np.concatenate(cnts), np.asarray(counts, dtype=np.uint32))
+    # wide keys + the package's own writer, read back in blocks of 7
+    rng = np.random.default_rng(1)
+    lo = np.sort(rng.integers(0, 1 << 62, 50, dtype=np.uint64)); hi = rng.integers(0, 1 << 20, 50, dtype=np.uint64)
+    cnt = rng.integers(1, 1000, 50).astype(np.uint32)
+    p2 = str(tmp_path / "w.jf")
+    jf_io.write_index(p2, 47, lo, hi, cnt)
+    got = list(jf_io.iter_index(p2, chunk_records=7))
+    assert len(got) == 8 and all(g[0] == 47 for g in got)
+    np.testing.assert_array_equal(np.concatenate([g[1] for g in got]), lo)
+    np.testing.assert_array_equal(np.concatenate([g[2] for g in got]), hi)
+    np.testing.assert_array_equal(np.concatenate([g[3] for g in got]), cnt)
+    k, rlo, rhi, rcnt = jf_io.read_index(p2)
+    assert k == 47 and np.array_equal(rlo, lo) and np.array_equal(rhi, hi) and np.array_equal(rcnt, cnt)
