@@ -6,10 +6,11 @@ engine's parent scan -- mirrors of ``kmer_denovo_filter/vcf/pipeline.py``:
     scan_parents            reference :1571-1622 (mother + father count --if, counts ADDED)
     annotate_variants       reference :1640-1724 (DKU / DKT / DKA, MIN/AVG/MAX_PKC[_ALT])
 
-The reference fetches reads per variant through the BAM index; this reader has no
-index support yet, so the child BAM is read once and reads are matched to the
-variants they overlap (fine for candidate lists; an index would be needed for
-whole-genome VCFs).
+The reference fetches reads per variant through the BAM index; this reader streams the
+child BAM once instead (multi-threaded inflate + parse, ~2.8 Gbase/s) and matches every
+batch against the sorted variant positions with numpy (`_records_over_positions`): only the
+records that overlap a variant ever become Python objects, so the cost above the stream is
+proportional to the variants, as with the index.
 """
 from __future__ import annotations
 
@@ -18,6 +19,8 @@ import gzip
 import logging
 import os
 import statistics
+
+import numpy as np
 
 from ..alignment import reads_from_batch
 from ..core.jellyfish_wrappers import _scan_parent_jellyfish
@@ -67,6 +70,44 @@ def _parse_vcf_variants(vcf_path, proband_id=None):
     return variants
 
 
+_REF_CONSUMING_OPS = np.zeros(16, dtype=np.int64)
+_REF_CONSUMING_OPS[[0, 2, 3, 7, 8]] = 1                       # M D N = X (pysam reference_end)
+
+
+def _records_over_positions(batch, refs, positions_by_chrom, eligible=None, empty_span_is_one=False):
+    """Indices (ascending) of the batch's records whose reference interval [start, end) holds at least one of the
+    sorted positions of its chromosome, and for each the index of the FIRST such position in that chromosome's list.
+    Vectorised over the batch: reference lengths from the CIGAR arrays, one searchsorted per chromosome."""
+    n = batch.n_reads
+    start = np.asarray(batch.positions[:n], dtype=np.int64)
+    cig = np.asarray(batch.cigar, dtype=np.uint32)
+    off = np.asarray(batch.cigar_offsets[:n + 1], dtype=np.int64)
+    if len(cig):
+        consumed = np.concatenate(([0], np.cumsum((cig >> 4).astype(np.int64) * _REF_CONSUMING_OPS[cig & 15])))
+        end = start + (consumed[off[1:]] - consumed[off[:-1]])
+    else:
+        end = start.copy()
+    if empty_span_is_one:
+        end = np.where(end <= start, start + 1, end)
+    rid = np.asarray(batch.ref_ids[:n], dtype=np.int64)
+    ok = np.ones(n, dtype=bool) if eligible is None else np.asarray(eligible, dtype=bool).copy()
+    hit = np.zeros(n, dtype=bool)
+    first = np.zeros(n, dtype=np.int64)
+    for r in np.unique(rid[ok]):
+        if r < 0 or r >= len(refs) or refs[r] not in positions_by_chrom:
+            continue
+        vp = positions_by_chrom[refs[r]]
+        if len(vp) == 0:
+            continue
+        idx = np.flatnonzero(ok & (rid == r))
+        j = np.searchsorted(vp, start[idx], side="left")
+        over = (j < len(vp)) & (vp[np.minimum(j, len(vp) - 1)] < end[idx])
+        hit[idx[over]] = True
+        first[idx[over]] = j[over]
+    keep = np.flatnonzero(hit)
+    return keep, first[keep]
+
+
 def _variant_key(var):
     return f"{var['chrom']}:{var['pos']}:{var['ref']}:{var['alt'] if var['alt'] is not None else '.'}"
 
@@ -79,15 +120,15 @@ def _collect_child_kmers(child_bam, ref_fasta, variants, kmer_size, min_baseq, m
     for v in variants:
         by_chrom[v["chrom"]].append(v)
     per_variant = {_variant_key(v): [] for v in variants}
+    vpos = {c: np.unique(np.asarray([v["pos"] for v in vs], dtype=np.int64)) for c, vs in by_chrom.items()}
     rd = bam_reader(child_bam, flag_off=0, collapse=False, max_bases=1 << 24, threads=4, want_aux=True)
     refs = rd.references()
     with rd:
         for batch in rd:
-            keep = [i for i in range(batch.n_reads)
-                    if not (int(batch.flags[i]) & (0x4 | 0x100 | 0x800 | 0x400))
-                    and int(batch.mapq[i]) >= min_mapq
-                    and 0 <= int(batch.ref_ids[i]) < len(refs) and refs[int(batch.ref_ids[i])] in by_chrom]
-            for read in reads_from_batch(batch, refs, keep):
+            n = batch.n_reads
+            eligible = ((np.asarray(batch.flags[:n]) & (0x4 | 0x100 | 0x800 | 0x400)) == 0) & (np.asarray(batch.mapq[:n]) >= min_mapq)
+            keep, _ = _records_over_positions(batch, refs, vpos, eligible)
+            for read in reads_from_batch(batch, refs, keep.tolist()):
                 rstart, rend = read.reference_start, read.reference_end
                 pairs = None
                 for var in by_chrom[read.reference_name]:
@@ -187,8 +228,6 @@ def _write_informative_reads(child_bam, ref_fasta, informative_reads_by_variant,
     record it meets per read name; the same record is picked here from one pass
     over the file: smallest (region rank, file order) among the records of that
     name overlapping a variant position."""
-    import bisect
-    from ..core.bam_scanner import reference_end
     from ..reads import write_bam_subset
     read_to_variants = {}
     for var_key, names in informative_reads_by_variant.items():
@@ -199,28 +238,21 @@ def _write_informative_reads(child_bam, ref_fasta, informative_reads_by_variant,
     by_chrom = collections.defaultdict(list)
     for c, p in regions:
         by_chrom[c].append(p)
+    vpos = {c: np.asarray(ps, dtype=np.int64) for c, ps in by_chrom.items()}      # (regions are sorted and unique)
     best = {}                                            # name -> (region rank, ordinal)
     rd = bam_reader(child_bam, flag_off=0, collapse=False, max_bases=1 << 24, threads=threads, want_aux=True)
     refs = rd.references()
     with rd:
         for batch in rd:
-            for i in range(batch.n_reads):
-                rid = int(batch.ref_ids[i])
-                if rid < 0 or refs[rid] not in by_chrom:
-                    continue
+            keep, first = _records_over_positions(batch, refs, vpos, None, empty_span_is_one=True)
+            for i, j in zip(keep.tolist(), first.tolist()):          # only records that overlap a variant position
                 name = batch.name(i)
                 if name not in read_to_variants:
                     continue
-                start = int(batch.positions[i])
-                end = reference_end(start, batch.cigartuples(i))
-                if end <= start:
-                    end = start + 1
-                plist = by_chrom[refs[rid]]
-                j = bisect.bisect_left(plist, start)
-                if j < len(plist) and plist[j] < end:
-                    cand = (rank[(refs[rid], plist[j])], int(batch.ordinals[i]))
-                    if name not in best or cand < best[name]:
-                        best[name] = cand
+                chrom = refs[int(batch.ref_ids[i])]
+                cand = (rank[(chrom, by_chrom[chrom][j])], int(batch.ordinals[i]))
+                if name not in best or cand < best[name]:
+                    best[name] = cand
     names = sorted(best, key=lambda n: best[n][1])
     aux = [b"DVZ" + ",".join(sorted(read_to_variants[n])).encode() + b"\0" for n in names]
     return write_bam_subset(child_bam, output_bam, [best[n][1] for n in names], aux, sort_and_index=True,
