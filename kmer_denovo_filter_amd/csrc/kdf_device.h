@@ -106,8 +106,13 @@ __device__ __forceinline__ uint64_t kdf_home(const KdfTable &t, uint64_t h) {
 //                // slots of a bucket a probe may visit before it turns to the overflow table
 // ORDER of the minimizer scheme: an injective 24-bit scramble (odd multiply mod 2^24, xor-shift) of the canonical
 // m-mer code.  Its top bits name the bucket, so they must be well mixed; one full-rate v_mul_u32_u24.
+// The code is XORed with a constant first: without it the homopolymer AAAAAAAAAAAA (canonical code 0) had order value 0,
+// the global minimum, so EVERY k-mer that merely touches a poly-A / poly-T run of 12 bases was sent to one bucket
+// (measured on a repeat-rich 100 Mbp genome: 167 M spills, a 765 ms pass).  With it a low-complexity m-mer wins a
+// window as often as any other, and only the windows that lie INSIDE a repeat (few distinct k-mers) keep it.
+#define KDF_SK_ORDER_XOR 0x5A3C96u
 __host__ __device__ __forceinline__ uint32_t kdf_sk_order(uint32_t cm) {
-    uint32_t g = (cm * 0x9E3779u) & 0xFFFFFFu;
+    uint32_t g = ((cm ^ KDF_SK_ORDER_XOR) * 0x9E3779u) & 0xFFFFFFu;
     return g ^ (g >> 11);
 }
 // minimizer order value of a canonical k-mer x (MSB-first code), k >= KDF_SK_M

@@ -420,7 +420,9 @@ __global__ __launch_bounds__(256) void sk_chunklist_kernel(SkScratch s) {
 // order value of a record's minimizer, from the stored offset
 __device__ __forceinline__ uint32_t sk_rec_order(uint64_t lo, uint64_t hi) {
     constexpr uint32_t MM = (1u << (2 * KDF_SK_M)) - 1;
-    const uint32_t e = (uint32_t)kdf_funnel(lo, hi & SK_HI_BASES, 2 * (int)SK_REC_OFF(hi)) & MM;   // m-mer, base i in bits 2i
+    // (offsets up to 40: a record that was stored reverse-complemented keeps its minimizer near its END when the run of one
+    // minimizer VALUE outlasted the first instance -- tandem repeats, homopolymers -- so the shift can reach 80 bits)
+    const uint32_t e = (uint32_t)sk_shr128(lo, hi & SK_HI_BASES, 2 * (int)SK_REC_OFF(hi)) & MM;   // m-mer, base i in bits 2i
     const uint32_t rc = ~e & MM;
     const uint32_t fw = sk_rev2_32(e) >> (32 - 2 * KDF_SK_M);
     return kdf_sk_order(fw < rc ? fw : rc);
