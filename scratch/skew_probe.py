@@ -25,7 +25,7 @@ genomes = {"uniform": synth_genome(G, 20260417, "cuda"), "repeat_rich": torch.fr
 for gname, g in genomes.items():
     ds = synth_stream(reads, 150, seed=20260417, device="cuda", genome=g)
     torch.cuda.synchronize()
-    for pname, path in (("binned", 2), ("superkmer", 3)):
+    for pname, path in (("binned", 2), ("superkmer", 3))[: int(os.environ.get("SKEW_PATHS", "2"))]:
         e = KmerEngine(31, capacity_hint=1 << 28)
         e.set_option("force_path", path)
         best = None
@@ -35,10 +35,14 @@ for gname, g in genomes.items():
             e.count_dev(ds.packed.data_ptr(), ds.invalid.data_ptr(), ds.n_bases); e.synchronize()
             dt = (time.perf_counter() - t0) * 1e3
             best = dt if best is None else min(best, dt)
+        e.clear(); e.profile(True)
+        e.count_dev(ds.packed.data_ptr(), ds.invalid.data_ptr(), ds.n_bases); e.synchronize()
+        stage_ms, _ = e.profile_stages(); names = e.profile_stage_names(); e.profile(False)
         cap, distinct, windows = e.stats()
         lo, hi, cnt = e.export_ge(1000)
         row = {"genome": gname, "path": pname, "wall_ms": round(best, 2), "Gkmer_per_s": round(windows / best / 1e6, 1), "windows": windows,
-               "distinct": distinct, "slots": cap, "kmers_ge1000": int(len(lo)), "max_count": int(cnt.max()) if len(cnt) else 0}
+               "distinct": distinct, "slots": cap, "kmers_ge1000": int(len(lo)), "max_count": int(cnt.max()) if len(cnt) else 0,
+               "stage_ms": {n: round(x, 2) for n, x in zip(names, stage_ms)}}
         for s in ("sk_spills", "sk_failed_buckets", "sk_passes", "ovf_log2cap", "replayed_buckets", "sk_fallbacks"):
             try: row[s] = e.get_stat(s)
             except Exception: pass
