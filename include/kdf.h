@@ -223,6 +223,12 @@ int kdf_export_ge_dev(kdf_engine *h, uint32_t min_count, void *d_keys_lo_out,
 int kdf_export_parts_dev(kdf_engine *h, uint32_t min_count, uint32_t parts, void *d_keys_lo_out,
                          void *d_keys_hi_out, void *d_counts_out, uint64_t cap,
                          uint64_t *part_counts_out, uint64_t *n_out);
+/* The same dump written straight into the buffer the all-to-all sends: part p is ONE byte segment
+ * [lo x n_p | hi x n_p (k > 32) | counts x n_p] starting at part_bytes_out[p] (multiples of 8; part_bytes_out[parts] =
+ * total bytes; cap_bytes >= n * (12 or 20) + 8 * parts always suffices).  A receiver hands the segments it got to
+ * kdf_add_pairs_multi_dev as they lie. */
+int kdf_export_parts_packed_dev(kdf_engine *h, uint32_t min_count, uint32_t parts, void *d_buf, uint64_t cap_bytes,
+                                uint64_t *part_counts_out, uint64_t *part_bytes_out, uint64_t *n_out);
 
 /* ------------------------------------------------------ Module-3 scan ---- */
 

@@ -52,6 +52,7 @@ SYMBOLS = [
     ("kdf_export_ge", c_int, [_P, c_uint32, _P, _P, _P, c_uint64, POINTER(c_uint64)]),
     ("kdf_export_ge_dev", c_int, [_P, c_uint32, _P, _P, _P, c_uint64, c_int, POINTER(c_uint64)]),
     ("kdf_export_parts_dev", c_int, [_P, c_uint32, c_uint32, _P, _P, _P, c_uint64, POINTER(c_uint64), POINTER(c_uint64)]),
+    ("kdf_export_parts_packed_dev", c_int, [_P, c_uint32, c_uint32, _P, c_uint64, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
     ("kdf_scan_reads", c_int, [_P, _P, _P, c_uint64, _P, c_int64, _P, _P]),
     ("kdf_scan_reads_dev", c_int, [_P, _P, _P, c_uint64, _P]),
     ("kdf_stream_words", None, [c_uint64, POINTER(c_uint64), POINTER(c_uint64)]),

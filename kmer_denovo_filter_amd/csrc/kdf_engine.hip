@@ -2004,52 +2004,74 @@ static int export_pass(kdf_engine *h, uint32_t min_count, bool write, uint64_t *
 }
 
 // The sender's half of the multi-GPU merge (kdf_merge.h): the table in hash order, one contiguous range per owner.
-int kdf_export_parts_dev(kdf_engine *h, uint32_t min_count, uint32_t parts, void *d_keys_lo_out, void *d_keys_hi_out,
-                         void *d_counts_out, uint64_t cap, uint64_t *part_counts_out, uint64_t *n_out) {
-    if (!h || !n_out || !part_counts_out) return fail(h, KDF_ERR_INVALID, "kdf_export_parts_dev: NULL pointer");
-    if (parts < 1 || parts > KDF_SHARDS) return fail(h, KDF_ERR_INVALID, "kdf_export_parts_dev: parts must be 1..%d", KDF_SHARDS);
+// packed: d_lo is the byte buffer of the packed layout, cap its size in bytes, part_bytes_out[parts + 1] the segment offsets.
+static int export_parts(kdf_engine *h, uint32_t min_count, uint32_t parts, bool packed, void *d_lo, void *d_hi, void *d_cnt,
+                        uint64_t cap, uint64_t *part_counts_out, uint64_t *part_bytes_out, uint64_t *n_out, const char *who) {
+    if (parts < 1 || parts > KDF_SHARDS) return fail(h, KDF_ERR_INVALID, "%s: parts must be 1..%d", who, KDF_SHARDS);
     HIPCHK(h, hipSetDevice(h->device));
     { int rc0 = materialize(h); if (rc0) return rc0; }
-    if (h->t.sk) return fail(h, KDF_ERR_STATE, "kdf_export_parts_dev: the table is minimizer-bucketed (owners are not slot ranges)");
-    if (h->t.hshift) return fail(h, KDF_ERR_STATE, "kdf_export_parts_dev: an owner table (hash_shift) is not dumped by owner again");
+    if (h->t.sk) return fail(h, KDF_ERR_STATE, "%s: the table is minimizer-bucketed (owners are not slot ranges)", who);
+    if (h->t.hshift) return fail(h, KDF_ERR_STATE, "%s: an owner table (hash_shift) is not dumped by owner again", who);
     if (h->t.log2cap < 28)                                  // an owner boundary (a 16-bit hash prefix) must be a block boundary
-        return fail(h, KDF_ERR_STATE, "kdf_export_parts_dev: table of 2^%u slots is too small for an owner-ordered dump (needs 2^28)", h->t.log2cap);
-    const bool have_out = d_keys_lo_out && (h->kw == 1 || d_keys_hi_out);
+        return fail(h, KDF_ERR_STATE, "%s: table of 2^%u slots is too small for an owner-ordered dump (needs 2^28)", who, h->t.log2cap);
+    const bool have_out = d_lo && (packed || h->kw == 1 || d_hi);
     const uint64_t nblk = h->cap / KM_BLOCK_SLOTS;
-    // scratch: blk_off u64[nblk + 1] | part_first u64[KDF_SHARDS] | part_off u64[KDF_SHARDS + 1] | blk_cnt u32[nblk]
-    const size_t off_words = nblk + 1 + KDF_SHARDS + KDF_SHARDS + 1;
+    // scratch: blk_off u64[nblk + 1] | part_first u64[S] | part_off u64[S + 1] | part_base u64[S + 1] | blk_cnt u32[nblk]
+    const size_t off_words = nblk + 1 + KDF_SHARDS + 2 * (KDF_SHARDS + 1);
     int rc = merge_reserve(h, off_words * 8 + nblk * 4);
     if (rc) return rc;
     unsigned long long *blk_off = (unsigned long long *)h->merge_buf;
     uint64_t *part_first = (uint64_t *)(blk_off + nblk + 1);
     unsigned long long *part_off = (unsigned long long *)(part_first + KDF_SHARDS);
-    uint32_t *blk_cnt = (uint32_t *)(part_off + KDF_SHARDS + 1);
+    unsigned long long *part_base = part_off + KDF_SHARDS + 1;
+    uint32_t *blk_cnt = (uint32_t *)(part_base + KDF_SHARDS + 1);
     std::vector<uint64_t> pf(KDF_SHARDS, 0);
     for (uint32_t p = 0; p < parts; ++p) {                  // first 16-bit hash prefix t with ((t * parts) >> 16) == p
         const uint64_t t16 = ((uint64_t)p * 65536 + parts - 1) / parts;
         pf[p] = (t16 << (h->t.log2cap - 16)) / KM_BLOCK_SLOTS;
     }
     HIPCHK(h, hipMemcpyAsync(part_first, pf.data(), KDF_SHARDS * 8, hipMemcpyHostToDevice, h->stream));
-    std::vector<unsigned long long> po(KDF_SHARDS + 1, 0);
+    std::vector<unsigned long long> po(2 * (KDF_SHARDS + 1), 0);
+    const uint32_t esz = 8u * h->kw + 4u;
     by_width(h, [&](auto KWc) {
         constexpr int KW = decltype(KWc)::value;
         hipLaunchKernelGGL(km_count_kernel<KW>, dim3((unsigned)nblk), dim3(KM_THREADS), 0, h->stream, h->t, min_count, blk_cnt);
         hipLaunchKernelGGL(km_scan_kernel, dim3(1), dim3(1024), 0, h->stream, blk_cnt, blk_off, nblk, part_first, parts, part_off);
-        if (have_out)
-            hipLaunchKernelGGL(km_write_kernel<KW>, dim3((unsigned)nblk), dim3(KM_THREADS), 0, h->stream, h->t, min_count, blk_off,
-                               (uint64_t *)d_keys_lo_out, h->kw == 2 ? (uint64_t *)d_keys_hi_out : nullptr, (uint32_t *)d_counts_out, cap);
+        hipLaunchKernelGGL(km_packbase_kernel, dim3(1), dim3(64), 0, h->stream, part_off, parts, esz, part_base);
+        if (have_out && packed)
+            hipLaunchKernelGGL((km_write_kernel<KW, true>), dim3((unsigned)nblk), dim3(KM_THREADS), 0, h->stream, h->t, min_count, blk_off,
+                               (uint64_t *)d_lo, (uint64_t *)nullptr, (uint32_t *)nullptr, cap, part_off, part_base, parts);
+        else if (have_out)
+            hipLaunchKernelGGL((km_write_kernel<KW, false>), dim3((unsigned)nblk), dim3(KM_THREADS), 0, h->stream, h->t, min_count, blk_off,
+                               (uint64_t *)d_lo, h->kw == 2 ? (uint64_t *)d_hi : nullptr, (uint32_t *)d_cnt, cap, part_off, part_base, parts);
         return 0;
     });
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(po.data(), part_off, (parts + 1) * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(po.data(), part_off, 2 * (KDF_SHARDS + 1) * 8, hipMemcpyDeviceToHost, h->stream));   // part_off | part_base
     HIPCHK(h, hipStreamSynchronize(h->stream));             // the one synchronisation of the dump (pf / po are pageable)
     const uint64_t n = po[parts];
     for (uint32_t p = 0; p < parts; ++p) part_counts_out[p] = po[p + 1] - po[p];
+    if (part_bytes_out) for (uint32_t p = 0; p <= parts; ++p) part_bytes_out[p] = po[KDF_SHARDS + 1 + p];
     *n_out = n;
     if (n == 0) return KDF_OK;
-    if (n > cap) return fail(h, KDF_ERR_INVALID, "kdf_export_parts_dev: %llu entries, room for %llu", (unsigned long long)n, (unsigned long long)cap);
-    if (!have_out) return fail(h, KDF_ERR_INVALID, "kdf_export_parts_dev: NULL key output");
+    const uint64_t need = packed ? po[KDF_SHARDS + 1 + parts] : n;
+    if (need > cap) return fail(h, KDF_ERR_INVALID, "%s: %llu %s, room for %llu", who, (unsigned long long)need, packed ? "bytes" : "entries", (unsigned long long)cap);
+    if (!have_out) return fail(h, KDF_ERR_INVALID, "%s: NULL output", who);
     return KDF_OK;
+}
+
+int kdf_export_parts_dev(kdf_engine *h, uint32_t min_count, uint32_t parts, void *d_keys_lo_out, void *d_keys_hi_out,
+                         void *d_counts_out, uint64_t cap, uint64_t *part_counts_out, uint64_t *n_out) {
+    if (!h || !n_out || !part_counts_out) return fail(h, KDF_ERR_INVALID, "kdf_export_parts_dev: NULL pointer");
+    return export_parts(h, min_count, parts, false, d_keys_lo_out, d_keys_hi_out, d_counts_out, cap, part_counts_out, nullptr, n_out,
+                        "kdf_export_parts_dev");
+}
+
+int kdf_export_parts_packed_dev(kdf_engine *h, uint32_t min_count, uint32_t parts, void *d_buf, uint64_t cap_bytes,
+                                uint64_t *part_counts_out, uint64_t *part_bytes_out, uint64_t *n_out) {
+    if (!h || !n_out || !part_counts_out || !part_bytes_out) return fail(h, KDF_ERR_INVALID, "kdf_export_parts_packed_dev: NULL pointer");
+    return export_parts(h, min_count, parts, true, d_buf, nullptr, nullptr, cap_bytes, part_counts_out, part_bytes_out, n_out,
+                        "kdf_export_parts_packed_dev");
 }
 
 int kdf_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes) {

@@ -88,11 +88,27 @@ __global__ __launch_bounds__(1024) void km_scan_kernel(const uint32_t *__restric
     if (tid <= parts && part_off) part_off[tid] = tid == parts ? carry : blk_off[part_first_blk[tid]];
 }
 
+// Packed layout of the dump (what the all-to-all sends): part p is ONE byte segment [lo x n_p | hi x n_p (wide) | counts x n_p],
+// segments back to back, each start rounded up to 8 bytes.  part_base[p] = byte offset of segment p (part_base[parts] = total).
+__global__ void km_packbase_kernel(const unsigned long long *__restrict__ part_off, uint32_t parts, uint32_t esz,
+                                   unsigned long long *__restrict__ part_base) {
+    if (threadIdx.x || blockIdx.x) return;
+    unsigned long long b = 0;
+    for (uint32_t p = 0; p < parts; ++p) {
+        part_base[p] = b;
+        b += ((part_off[p + 1] - part_off[p]) * esz + 7ull) & ~7ull;
+    }
+    part_base[parts] = b;
+}
+
 // pass 2: a block's kept entries, grouped by the KM_SUB_BITS hash bits below the block prefix, at blk_off[block]
-template <int KW>
+// PACKED: olo is the byte buffer of the packed layout (km_packbase_kernel), out_cap its size in bytes; a block lies in one part.
+template <int KW, bool PACKED>
 __global__ __launch_bounds__(KM_THREADS) void km_write_kernel(KdfTable t, uint32_t min_count, const unsigned long long *__restrict__ blk_off,
                                                               uint64_t *__restrict__ olo, uint64_t *__restrict__ ohi,
-                                                              uint32_t *__restrict__ ocnt, uint64_t out_cap) {
+                                                              uint32_t *__restrict__ ocnt, uint64_t out_cap,
+                                                              const unsigned long long *__restrict__ part_off,
+                                                              const unsigned long long *__restrict__ part_base, uint32_t parts) {
     constexpr uint32_t NB = 1u << KM_SUB_BITS;
     const uint64_t cap = 1ull << t.log2cap;
     const uint64_t first = (uint64_t)blockIdx.x * KM_BLOCK_SLOTS;
@@ -100,6 +116,15 @@ __global__ __launch_bounds__(KM_THREADS) void km_write_kernel(KdfTable t, uint32
     if (blk_off[blockIdx.x + 1] == base) return;
     __shared__ uint32_t hist[NB], start[NB];
     if (threadIdx.x < NB) hist[threadIdx.x] = 0;
+    // packed: this block's part (owner of the 16-bit hash prefix of its first slot), its pair range and byte segment
+    unsigned long long p_first = 0, p_n = 0; char *seg = nullptr;
+    if constexpr (PACKED) {
+        const uint32_t part = (uint32_t)((((first >> (t.log2cap - 16)) & 0xFFFFu) * parts) >> 16);
+        p_first = part_off[part]; p_n = part_off[part + 1] - p_first;
+        const unsigned long long pb = part_base[part];
+        if (pb + ((p_n * (8ull * KW + 4ull) + 7ull) & ~7ull) > out_cap) return;          // (the host checks the total and fails the call)
+        seg = (char *)olo + pb;
+    }
     __syncthreads();
     // the block prefix is the top (log2cap - 12) hash bits (fewer than 12 bits of table: one block, no prefix)
     const uint32_t pre_bits = t.log2cap > 12 ? t.log2cap - 12 : 0;
@@ -131,7 +156,12 @@ __global__ __launch_bounds__(KM_THREADS) void km_write_kernel(KdfTable t, uint32
     for (uint32_t r = 0; r < KM_SPT; ++r) {
         if (sub[r] != 0xFFFFFFFFu) {
             const uint64_t pos = base + start[sub[r]] + rank[r];
-            if (pos < out_cap) {
+            if constexpr (PACKED) {
+                const uint64_t i = pos - p_first;
+                ((uint64_t *)seg)[i] = lo[r];
+                if (KW == 2) ((uint64_t *)seg)[p_n + i] = hi[r];
+                ((uint32_t *)(seg + p_n * 8ull * KW))[i] = c[r];
+            } else if (pos < out_cap) {
                 olo[pos] = lo[r];
                 if (KW == 2 && ohi) ohi[pos] = hi[r];
                 if (ocnt) ocnt[pos] = c[r];

@@ -130,6 +130,20 @@ class EngineOps(TableOps):
         self.e.synchronize()
         return lo[:n], (hi[:n] if hi is not None else None), cnt[:n], counts
 
+    def export_packed_by_owner(self, world: int):
+        """(send buffer uint8, per-owner pair counts, per-owner byte offsets [world + 1]): the owner-ordered dump written
+        by the engine straight into the layout `OwnerPartitionedCount.exchange` sends -- no (lo, hi, cnt) temporaries, no
+        packing copies.  None when the table cannot be dumped by owner (see export_pairs_by_owner)."""
+        if self.e.get_stat("layout") != 0 or self.e.get_stat("log2cap") < 28 or world > 64 or self.e.get_stat("hash_shift"):
+            return None
+        _, distinct, _ = self.e.stats()
+        cap = distinct * (20 if self.wide else 12) + 8 * world + 8
+        buf = torch.empty(cap, dtype=torch.uint8, device=self.device)
+        self._sync()
+        n, counts, offs = self.e.export_parts_packed_dev(0, world, buf.data_ptr(), cap)
+        self.e.synchronize()
+        return buf[:offs[world]], counts, offs
+
     def add_pairs(self, lo, hi, cnt):
         if lo.numel() == 0:
             return
@@ -259,44 +273,53 @@ class OwnerPartitionedCount:
         packed all-to-all (per destination a byte segment [lo words | hi words | counts], starts aligned to 8)."""
         if self.world == 1:
             return
-        grouped = self.local.export_pairs_by_owner(self.world) if hasattr(self.local, "export_pairs_by_owner") else None
-        if grouped is not None:                      # the engine dumps owner by owner: nothing to sort
-            lo, hi, cnt, counts = grouped
-            send_counts = torch.tensor(counts, dtype=torch.int64)
-        else:
-            lo, hi, cnt = self.local.export_pairs(0)
-            own = owner_of(lo, hi, self.world)
-            order = torch.argsort(own, stable=True)
-            lo, cnt = lo[order], cnt[order]
-            hi = hi[order] if hi is not None else None
-            send_counts = torch.bincount(own, minlength=self.world).to(torch.int64).cpu()
+        packed = self.local.export_packed_by_owner(self.world) if hasattr(self.local, "export_packed_by_owner") else None
+        wide = bool(getattr(self.local, "wide", False))
+        esz = 20 if wide else 12
         cdev = torch.device("cpu") if self.host else self.device
+        if packed is not None:                       # the engine wrote the send buffer itself, owner by owner, in hash order
+            send, s_list, offs = packed
+            s_bytes = [offs[p + 1] - offs[p] for p in range(self.world)]
+            send_counts = torch.tensor(s_list, dtype=torch.int64)
+        else:
+            grouped = self.local.export_pairs_by_owner(self.world) if hasattr(self.local, "export_pairs_by_owner") else None
+            if grouped is not None:                  # the engine dumps owner by owner: nothing to sort
+                lo, hi, cnt, counts = grouped
+                send_counts = torch.tensor(counts, dtype=torch.int64)
+            else:
+                lo, hi, cnt = self.local.export_pairs(0)
+                own = owner_of(lo, hi, self.world)
+                order = torch.argsort(own, stable=True)
+                lo, cnt = lo[order], cnt[order]
+                hi = hi[order] if hi is not None else None
+                send_counts = torch.bincount(own, minlength=self.world).to(torch.int64).cpu()
+            wide = hi is not None
+            esz = 20 if wide else 12
+            s_list = send_counts.tolist()
+            s_bytes = [_round8(n * esz) for n in s_list]
+            send = torch.empty(sum(s_bytes), dtype=torch.uint8, device=lo.device)
+            off = a = 0
+            for n, nb in zip(s_list, s_bytes):       # 2-3 contiguous device copies per destination
+                if n:
+                    send[off:off + 8 * n].view(torch.int64).copy_(lo[a:a + n])
+                    o2 = off + 8 * n
+                    if hi is not None:
+                        send[o2:o2 + 8 * n].view(torch.int64).copy_(hi[a:a + n])
+                        o2 += 8 * n
+                    send[o2:o2 + 4 * n].view(torch.int32).copy_(cnt[a:a + n])
+                off += nb
+                a += n
         sc = send_counts.to(cdev)
         rc = torch.empty_like(sc)
         dist.all_to_all_single(rc, sc, group=self.group)
-        s_list: List[int] = send_counts.tolist()
         r_list: List[int] = rc.tolist()
         self.last_exchange_pairs = int(sum(s_list))
-        esz = 20 if hi is not None else 12
-        s_bytes = [_round8(n * esz) for n in s_list]
         r_bytes = [_round8(n * esz) for n in r_list]
-        send = torch.empty(sum(s_bytes), dtype=torch.uint8, device=lo.device)
-        off = a = 0
-        for n, nb in zip(s_list, s_bytes):           # 2-3 contiguous device copies per destination
-            if n:
-                send[off:off + 8 * n].view(torch.int64).copy_(lo[a:a + n])
-                o2 = off + 8 * n
-                if hi is not None:
-                    send[o2:o2 + 8 * n].view(torch.int64).copy_(hi[a:a + n])
-                    o2 += 8 * n
-                send[o2:o2 + 4 * n].view(torch.int32).copy_(cnt[a:a + n])
-            off += nb
-            a += n
         src = send.cpu() if self.host else send
         recv = torch.empty(sum(r_bytes), dtype=torch.uint8, device=src.device)
         dist.all_to_all_single(recv, src, output_split_sizes=r_bytes, input_split_sizes=s_bytes, group=self.group)
         if self.host:
-            recv = recv.to(lo.device)
+            recv = recv.to(send.device)
         off = 0
         segments = []
         for n, nb in zip(r_list, r_bytes):           # the owner sums straight from the received segments, all sources at once
@@ -304,7 +327,7 @@ class OwnerPartitionedCount:
                 rlo = recv[off:off + 8 * n].view(torch.int64)
                 o2 = off + 8 * n
                 rhi = None
-                if hi is not None:
+                if wide:
                     rhi = recv[o2:o2 + 8 * n].view(torch.int64)
                     o2 += 8 * n
                 segments.append((rlo, rhi, recv[o2:o2 + 4 * n].view(torch.int32)))

@@ -260,6 +260,16 @@ class KmerEngine:
                                                 c_void_p(d_cnt) if d_cnt else None, int(cap), counts, byref(n)))
         return n.value, [int(x) for x in counts]
 
+    def export_parts_packed_dev(self, min_count: int, parts: int, d_buf: int, cap_bytes: int):
+        """The owner-ordered dump written into the packed all-to-all layout; returns (entries, per-owner counts,
+        segment byte offsets [parts + 1])."""
+        n = c_uint64(0)
+        counts = (c_uint64 * int(parts))()
+        offs = (c_uint64 * (int(parts) + 1))()
+        self._ck(self._lib.kdf_export_parts_packed_dev(self._h, int(min_count), int(parts), c_void_p(d_buf), int(cap_bytes),
+                                                       counts, offs, byref(n)))
+        return n.value, [int(x) for x in counts], [int(x) for x in offs]
+
     # -- Module-3 scan -----------------------------------------------------
     def scan(self, stream: ReadStream, want_distinct: bool = True):
         """-> (hit_bits uint64[mask words], distinct uint32[n_reads] or None)."""

@@ -19,6 +19,7 @@ def T(fn):
 for it in range(3):
     own.clear()
     (lo, hi, cnt, counts), t_exp = T(lambda: ops.export_pairs_by_owner(world))
+    _, t_pack = T(lambda: ops.export_packed_by_owner(world))
     # `world` sources, each a hash-ordered eighth of the dump (pair i -> source i % world): what an owner sees, at full size
     segs = [(lo[s::world].contiguous(), None, cnt[s::world].contiguous()) for s in range(world)]
     _, t_add = T(lambda: oops.add_pairs_segments(segs))
@@ -30,6 +31,6 @@ for it in range(3):
         p = torch.randperm(lo.numel(), device=dev)
         l2, c2 = lo[p].contiguous(), cnt[p].contiguous()
         t_rand = T(lambda: oops.add_pairs(l2, None, c2))[1]
-    print(json.dumps({"world": world, "pairs": int(lo.numel()), "export_parts_ms": round(t_exp, 2), "merge_fresh_ms": round(t_add, 2),
+    print(json.dumps({"world": world, "pairs": int(lo.numel()), "export_parts_ms": round(t_exp, 2), "export_packed_ms": round(t_pack, 2), "merge_fresh_ms": round(t_add, 2),
                       "merge_live_ms": round(t_add2, 2), "path": path, "add_pairs_random_order_ms": t_rand and round(t_rand, 2),
                       "owner_stats": own.stats()}))

@@ -146,3 +146,40 @@ def test_hash_shift_only_on_an_empty_table():
         assert e.get_stat("hash_shift") == 2
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("k", [31, 63])
+def test_packed_dump_is_the_send_buffer(k):
+    """kdf_export_parts_packed_dev writes what the exchange would otherwise assemble with copies: per owner one byte
+    segment [lo | hi | counts], starts on multiples of 8."""
+    import torch
+    from kmer_denovo_filter_amd.distributed import EngineOps
+    e = _counted_engine(k)
+    try:
+        ops = EngineOps(e, torch.device("cuda:0"))
+        world = 8
+        lo, hi, cnt, counts = ops.export_pairs_by_owner(world)
+        buf, pcounts, offs = ops.export_packed_by_owner(world)
+        assert pcounts == counts and offs[0] == 0 and buf.numel() == offs[world]
+        esz = 20 if k > 32 else 12
+        a = 0
+        for p, n in enumerate(counts):
+            assert offs[p] % 8 == 0 and offs[p + 1] - offs[p] == (n * esz + 7) // 8 * 8
+            seg = buf[offs[p]:offs[p + 1]]
+            slo = seg[:8 * n].view(torch.int64)
+            o = 8 * n
+            # (inside a 4096-slot block the order of equal sub-bins is not fixed between two dumps: compare as sorted triples)
+            if k > 32:
+                shi = seg[o:o + 8 * n].view(torch.int64); o += 8 * n
+            scnt = seg[o:o + 4 * n].view(torch.int32)
+            def ordered(l, h, c):
+                o = torch.argsort(l, stable=True)
+                if h is not None:
+                    o = o[torch.argsort(h[o], stable=True)]
+                return l[o], (h[o] if h is not None else None), c[o]
+            rl, rh, rc = ordered(lo[a:a + n], hi[a:a + n] if k > 32 else None, cnt[a:a + n])
+            gl, gh, gc = ordered(slo, shi if k > 32 else None, scnt)
+            assert torch.equal(rl, gl) and torch.equal(rc, gc) and (k <= 32 or torch.equal(rh, gh))
+            a += n
+    finally:
+        e.close()
