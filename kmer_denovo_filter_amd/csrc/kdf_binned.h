@@ -266,6 +266,10 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scan1_kernel(KbPlan plan, KbScr
             acc += n; cacc += (n + chunk - 1) / chunk;
         }
         a[nb] = acc; c[nb] = cacc;
+        unsigned long long mx = 0;
+        for (int i = 0; i < nb; ++i) mx = s.hist1[i] > mx ? s.hist1[i] : mx;
+        // skewed: one coarse bin holds more than twice its share (a uniform hash keeps the bins within a few per cent)
+        s.totals[7] = (nb > 1 && mx * (unsigned long long)nb > 2 * acc + 65536ull * nb) ? 1ull : 0ull;
         s.totals[0] = acc; s.totals[1] = cacc; s.totals[2] = 0; s.totals[3] = 0; s.failed_flag[0] = 0;
         for (int i = 9; i < 16; ++i) s.totals[i] = 0;          // diagnostic stamps
         if (acc) atomicAdd(&ctl->windows[0], acc);
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_cellscan_kernel(KbPlan plan, Kb
     const int nb = 1 << plan.c1;
     for (int i = threadIdx.x; i <= nb; i += KB_THREADS) { s.chunk_first[i] = (unsigned long long)i * n_wg; s.bin_start[i] = (unsigned long long)i * n_wg * chunk_entries; }
     if (threadIdx.x == 0) {
-        s.totals[0] = 0; s.totals[1] = (unsigned long long)nb * n_wg; s.totals[2] = 0; s.totals[3] = 0; s.totals[5] = 0; s.totals[6] = 0;
+        s.totals[0] = 0; s.totals[1] = (unsigned long long)nb * n_wg; s.totals[2] = 0; s.totals[3] = 0; s.totals[5] = 0; s.totals[6] = 0; s.totals[7] = 0;
         for (int i = 9; i < 16; ++i) s.totals[i] = 0;             // (totals[8] holds failed_flag: the host cleared it)
     }
 }
@@ -689,7 +693,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_poolscan_kernel(KbPlan plan, Kb
             acc += n; gacc += (n + KB_GROUP - 1) / KB_GROUP;
         }
         a[nb] = acc; g[nb] = gacc;
-        s.totals[0] = (unsigned long long)acc * (chunk_entries / KB_GROUP); s.totals[1] = gacc; s.totals[2] = 0; s.totals[3] = 0; s.failed_flag[0] = 0;
+        s.totals[7] = 0; s.totals[0] = (unsigned long long)acc * (chunk_entries / KB_GROUP); s.totals[1] = gacc; s.totals[2] = 0; s.totals[3] = 0; s.failed_flag[0] = 0;
         for (int i = 9; i < 16; ++i) s.totals[i] = 0;
     }
     __syncthreads();
@@ -788,21 +792,23 @@ __device__ __forceinline__ void kb_lds_sat_add(uint32_t *p, uint32_t add) {
     if (old + add < old || old + add == 0xFFFFFFFFu) atomicMax(p, 0xFFFFFFFFu);
 }
 
-// count += 1 at LDS slot sl for the lanes with `hit` (the whole wave calls it together).  When every hit lane names the
-// SAME slot -- a key of enormous multiplicity: a homopolymer k-mer took 1.4 % of all windows of a repeat-rich genome, all
-// of them in one workgroup -- one lane adds the lot instead of 64 adds serialising on one LDS address.  Measured: kernel C
-// 4.55 -> 4.69 ms on the uniform bench genome (the test costs every wave ~5 instructions per key), 14.6 -> 10.2 ms on the
-// repeat-rich one (pass 24.8 -> 20.4 ms); what remains there is one workgroup walking 15.9 M entries alone.
+// count += 1 at LDS slot sl for the lanes with `hit` (the whole wave calls it together).  AGG: when every hit lane names
+// the SAME slot -- a key of enormous multiplicity: a homopolymer k-mer took 1.4 % of all windows of a repeat-rich genome, all
+// of them in one workgroup -- one lane adds the lot instead of 64 adds serialising on one LDS address (kernel C 14.6 -> 10.2
+// ms there, pass 24.8 -> 20.4 ms).  The test costs every wave ~8 instructions per key (+3 % on the kernel for a uniform
+// genome), so it lives in its own instantiation of the kernel (VAR 2), which runs only when the coarse histogram is skewed
+// (kb_scan1_kernel sets totals[7]); both instantiations are launched, the one that does not apply returns at once.
+template <bool AGG>
 __device__ __forceinline__ void kb_count_hits(uint32_t *tcnt, uint32_t sl, bool hit) {
-#ifndef KB_C_NO_AGG
-    const unsigned long long hm = __ballot(hit);
-    if (hm == 0) return;
-    const uint32_t s0 = (uint32_t)__shfl((int)sl, __ffsll(hm) - 1);
-    if (__ballot(hit && sl != s0) == 0) {
-        if ((threadIdx.x & 63u) == (uint32_t)(__ffsll(hm) - 1)) atomicAdd(&tcnt[s0], (uint32_t)__popcll(hm));
-        return;
+    if constexpr (AGG) {
+        const unsigned long long hm = __ballot(hit);
+        if (hm == 0) return;
+        const uint32_t s0 = (uint32_t)__shfl((int)sl, __ffsll(hm) - 1);
+        if (__ballot(hit && sl != s0) == 0) {
+            if ((threadIdx.x & 63u) == (uint32_t)(__ffsll(hm) - 1)) atomicAdd(&tcnt[s0], (uint32_t)__popcll(hm));
+            return;
+        }
     }
-#endif
     if (hit) atomicAdd(&tcnt[sl], 1u);
 }
 
@@ -915,6 +921,9 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
     // (f, f + 1 of one coarse bin) read neighbouring runs of the same chunks -- they share the cache line at every run
     // boundary and the lines of the offset table -- so an XCD takes a contiguous eighth of the buckets, in order.
     if (s.failed_flag[0]) return;                              // the partition is not usable (a cell overflowed / the stream changed): the host knows
+    if constexpr (VAR >= 1 && MODE != KB_MODE_REPLAY) {
+        if ((VAR == 2) != (s.totals[7] != 0)) return;          // the other instantiation handles this pass (kb_count_hits)
+    }
     if (plan.cells && MODE != KB_MODE_REPLAY && blockIdx.x == 0 && threadIdx.x == 0 && s.totals[5])
         atomicAdd(&ctl->windows[0], s.totals[5]);              // the valid windows the cell scatter counted
     const uint32_t nbk = gridDim.x;
@@ -1147,7 +1156,7 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
                             else { more = true; sl = (sl + 1) & bmask; }
                         }                                            // FILTERED: absent, nothing to do
                     }
-                    kb_count_hits(tcnt, sl, hit);
+                    kb_count_hits<VAR == 2>(tcnt, sl, hit);
                     {
                         const unsigned long long mk = __ballot(more);
                         if (mk) {
@@ -1228,7 +1237,7 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
                             }
                         }                                                    // FILTERED: absent
                     }
-                    kb_count_hits(tcnt, sl, hit);
+                    kb_count_hits<VAR == 2>(tcnt, sl, hit);
                     const unsigned long long mk = __ballot(more);
                     if (mk) {
                         const uint32_t at = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));

@@ -719,6 +719,7 @@ static int kb_set_lds_attrs(kdf_engine *h, size_t a1, size_t b, size_t c) {
     HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_INSERT, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(c + KB_C_QEXTRA(V, KW)))); \
     HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_FILTERED, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(c + KB_C_QEXTRA(V, KW))));
     KB_SETV(1)
+    KB_SETV(2)
 #undef KB_SETV
     return KDF_OK;
 }
@@ -905,7 +906,7 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     const int nonempty = h->lazy_empty ? 0 : 1;   // 0: kernel C rewrites every bucket (this IS the clear)
     if (filtered)
 #define KB_LV(M, V) hipLaunchKernelGGL((kb_bucket_kernel<KW, M, V>), dim3((unsigned)nb_table), dim3(KB_C_CT(KW)), lds_c + KB_C_QEXTRA(V, KW), h->stream, plan, s, h->t, h->ctl, nonempty)
-#define KB_LVS(M) KB_LV(M, 1)
+#define KB_LVS(M) do { KB_LV(M, 1); KB_LV(M, 2); } while (0)      /* VAR 2 = VAR 1 + aggregated count adds; the device picks one (totals[7]) */
         if (var1) KB_LVS(KB_MODE_FILTERED);
         else hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_FILTERED, 0>), dim3((unsigned)nb_table), dim3(KB_C_CT(KW)), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty);
     else

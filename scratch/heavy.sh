@@ -1,6 +1,8 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-KDF_EXTRA_FLAGS="-DKB_C_AGG" python -m kmer_denovo_filter_amd.build --force > /dev/null 2>gpurun_out/build.err
+timeout -k 10 900 python -m pytest tests/test_gpu_parity_basic.py tests/test_gpu_scale.py tests/test_gpu_fuzz.py tests/test_gpu_superkmer.py tests/test_gpu_configs.py -x -q 2>&1 | tail -3 && \
+timeout -k 10 300 python bench.py --steps 20 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['stage_avg_ms'])" && \
+timeout -k 10 300 python bench.py --k 63 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['stage_avg_ms'])" && \
 SKEW_PATHS=1 timeout -k 10 600 python scratch/skew_probe.py 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
