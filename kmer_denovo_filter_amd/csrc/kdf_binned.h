@@ -100,7 +100,15 @@ struct KbScratch {
     uint32_t *bin_chunk_start;      // [2^c1 + 1]
     uint32_t *pool_ctr;             // [0] chunks taken
     uint32_t max_chunks, pad2;
+    // heavy buckets of a skewed pass (kb_heavy_slice_kernel): [0] how many, their ids, staged (key, count) pairs
+    uint32_t *hv_ctr;               // [4]
+    uint32_t *hv_bucket, *hv_n, *hv_failed;   // [KB_HV_MAX]
+    uint64_t *hv_key;               // [KB_HV_MAX][KB_HV_SLICES << 12]
+    uint32_t *hv_cnt;
 };
+#define KB_HV_MAX    64u                             // heavy buckets split per pass (further ones are processed the ordinary way)
+#define KB_HV_SLICES 32u                             // workgroups that share one heavy bucket's runs
+#define KB_C_HEAVY   65536u                          // entries (first 256 runs) from which a bucket counts as heavy: ~7x a bucket's share at bench load
 #define KB_GROUP 32                                  // pool chunks per fine-sort group
 #define KB_PCH(KW) (KbCfg<KW>::CHUNK / KB_GROUP)     // entries per pool chunk: 4 KB for either key width
 #define KB_NOCHUNK 0xFFFFFFFFu
@@ -270,9 +278,13 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scan1_kernel(KbPlan plan, KbScr
         for (int i = 0; i < nb; ++i) mx = s.hist1[i] > mx ? s.hist1[i] : mx;
         // skewed: one coarse bin holds more than twice its share (a uniform hash keeps the bins within a few per cent)
         s.totals[7] = (nb > 1 && mx * (unsigned long long)nb > 2 * acc + 65536ull * nb) ? 1ull : 0ull;
-        s.totals[0] = acc; s.totals[1] = cacc; s.totals[2] = 0; s.totals[3] = 0; s.failed_flag[0] = 0;
+        s.totals[0] = acc; s.totals[1] = cacc; s.totals[2] = 0; s.totals[3] = 0; s.totals[4] = 0; s.failed_flag[0] = 0;
         for (int i = 9; i < 16; ++i) s.totals[i] = 0;          // diagnostic stamps
         if (acc) atomicAdd(&ctl->windows[0], acc);
+    }
+    if (s.hv_ctr) {
+        if (threadIdx.x == 0) s.hv_ctr[0] = 0;
+        if (threadIdx.x < KB_HV_MAX) { s.hv_n[threadIdx.x] = 0; s.hv_failed[threadIdx.x] = 0; }
     }
     __syncthreads();
     for (int i = threadIdx.x; i <= nb; i += KB_THREADS) { s.bin_start[i] = a[i]; s.chunk_first[i] = c[i]; }
@@ -450,7 +462,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_cellscan_kernel(KbPlan plan, Kb
     const int nb = 1 << plan.c1;
     for (int i = threadIdx.x; i <= nb; i += KB_THREADS) { s.chunk_first[i] = (unsigned long long)i * n_wg; s.bin_start[i] = (unsigned long long)i * n_wg * chunk_entries; }
     if (threadIdx.x == 0) {
-        s.totals[0] = 0; s.totals[1] = (unsigned long long)nb * n_wg; s.totals[2] = 0; s.totals[3] = 0; s.totals[5] = 0; s.totals[6] = 0; s.totals[7] = 0;
+        s.totals[0] = 0; s.totals[1] = (unsigned long long)nb * n_wg; s.totals[2] = 0; s.totals[3] = 0; s.totals[4] = 0; s.totals[5] = 0; s.totals[6] = 0; s.totals[7] = 0;
         for (int i = 9; i < 16; ++i) s.totals[i] = 0;             // (totals[8] holds failed_flag: the host cleared it)
     }
 }
@@ -693,7 +705,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_poolscan_kernel(KbPlan plan, Kb
             acc += n; gacc += (n + KB_GROUP - 1) / KB_GROUP;
         }
         a[nb] = acc; g[nb] = gacc;
-        s.totals[7] = 0; s.totals[0] = (unsigned long long)acc * (chunk_entries / KB_GROUP); s.totals[1] = gacc; s.totals[2] = 0; s.totals[3] = 0; s.failed_flag[0] = 0;
+        s.totals[7] = 0; s.totals[4] = 0; s.totals[0] = (unsigned long long)acc * (chunk_entries / KB_GROUP); s.totals[1] = gacc; s.totals[2] = 0; s.totals[3] = 0; s.failed_flag[0] = 0;
         for (int i = 9; i < 16; ++i) s.totals[i] = 0;
     }
     __syncthreads();
@@ -985,6 +997,27 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
         }
         uint32_t total = 0;
         const uint32_t ex = kb_block_exscan(len, wsum, &total);
+        if constexpr (VAR == 2 && KW == 1 && MODE == KB_MODE_INSERT) {
+            // A heavy bucket (a few keys of enormous multiplicity) is not for ONE workgroup: it is left untouched here, as
+            // a failed bucket would be, and KB_HV_SLICES workgroups share its runs afterwards (kb_heavy_slice_kernel).
+            if (jb == j0 && total > KB_C_HEAVY && s.hv_ctr && !plan.cells && plan.sub_bits == 0 && plan.bucket_bits == 12) {   // (the host launches the heavy kernels under the same conditions)
+                if (threadIdx.x == 0) {
+                    const uint32_t idx = atomicAdd(&s.hv_ctr[0], 1u);
+                    sh_failed = idx;                          // (borrowed as a broadcast word; restored below)
+                    if (idx < KB_HV_MAX) s.hv_bucket[idx] = (uint32_t)bucket;
+                }
+                __syncthreads();
+                const bool taken = sh_failed < KB_HV_MAX;
+                __syncthreads();
+                if (threadIdx.x == 0) sh_failed = 0;
+                if (taken) {
+                    if (!table_nonempty)
+                        for (uint32_t i = threadIdx.x; i < B; i += CT) { t.lo[slot0 + i] = KDF_EMPTY; t.cnt[slot0 + i] = 0; }
+                    return;
+                }
+                __syncthreads();
+            }
+        }
         if (threadIdx.x < KB_C_RUNS) { run_pref[threadIdx.x] = ex; run_first[threadIdx.x] = first; if constexpr (KW == 2) run_hi[threadIdx.x] = hioff; }
         if constexpr (VAR >= 1) {
             if (threadIdx.x < KB_C_RUNS + 3) rpw[threadIdx.x + 1] = ex;     // threads past the last run hold ex == total
@@ -1339,3 +1372,135 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
     if (threadIdx.x == 0 && sh_claimed)
         atomicAdd(&ctl->distinct[(bucket % KDF_SHARDS) * 16], (unsigned long long)sh_claimed);
 }
+
+
+// ---------------------------------------------------------------------------
+// Heavy buckets of a skewed pass (narrow keys, insert mode; see kb_count_hits).  kb_bucket_kernel<.., VAR 2> lists the
+// buckets whose first 256 runs alone hold more than KB_C_HEAVY entries and leaves them untouched.  Here KB_HV_SLICES
+// workgroups share such a bucket's runs (run r to slice r % KB_HV_SLICES), each counting into a PRIVATE empty LDS table,
+// and stage their distinct (key, count) pairs; kb_heavy_combine_kernel then folds the staged pairs into the bucket the way
+// kernel C would have: slice in LDS, transactional (no room: the bucket is flagged for the replay pass and stays as it was).
+// Measured on the repeat-rich genome (one bucket of 15.9 M entries): kernel C 10.0 -> see DESIGN.md section 3.4.
+__global__ __launch_bounds__(256) void kb_heavy_slice_kernel(KbPlan plan, KbScratch s) {
+    constexpr int CHUNK = KbCfg<1>::CHUNK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (!s.hv_ctr || s.totals[7] == 0 || s.failed_flag[0]) return;
+    const uint32_t nh = min(s.hv_ctr[0], KB_HV_MAX), h = blockIdx.y, slice = blockIdx.x;
+    if (h >= nh) return;
+    const uint32_t B = 1u << plan.bucket_bits, bmask = B - 1;
+    uint64_t *tlo = (uint64_t *)smem;
+    uint32_t *tcnt = (uint32_t *)(smem + (size_t)B * 8);
+    __shared__ uint32_t sh_fail, sh_n, sh_base;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    for (uint32_t i = tid; i < B; i += 256) { tlo[i] = KDF_EMPTY; tcnt[i] = 0; }
+    if (tid == 0) { sh_fail = 0; sh_n = 0; }
+    __syncthreads();
+    const uint64_t bucket = s.hv_bucket[h];
+    const uint32_t c = (uint32_t)(bucket >> plan.c2), f = (uint32_t)(bucket & ((1u << plan.c2) - 1));
+    const unsigned long long j0 = s.chunk_first[c], j1 = s.chunk_first[c + 1], bstart = s.bin_start[c];
+    uint32_t claimed = 0; bool failed = false;
+    for (unsigned long long j = j0 + slice; j < j1; j += KB_HV_SLICES) {
+        const uint32_t r0 = s.chunk_off[j * plan.off_stride + f], r1 = s.chunk_off[j * plan.off_stride + f + 1];
+        const uint64_t *ent = s.ent_lo + bstart + (j - j0) * (unsigned long long)CHUNK + r0;
+        const uint32_t n = r1 - r0;
+        constexpr int U = 8;                                       // entries per thread in flight: one workgroup has to cover the HBM latency alone
+        for (uint32_t i0 = 0; i0 < n; i0 += 256 * U) {             // whole waves: the hit counting is a wave operation
+            uint64_t keys[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const uint32_t i = i0 + u * 256 + tid; keys[u] = i < n ? ent[i] : 0; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (i0 + u * 256 >= n) break;                      // (uniform)
+                const bool todo = i0 + u * 256 + tid < n;
+                const uint64_t key = keys[u];
+                const uint32_t sl = (uint32_t)(kdf_hash(key, 0) >> (64 - plan.log2cap)) & bmask;
+                const bool hit = todo && tlo[sl] == key;           // the heavy key sits in its home slot after its first insertion
+                kb_count_hits<true>(tcnt, sl, hit);
+                if (todo && !hit) {
+                    // (one slot per step is enough here: almost every entry took the branch above)
+                    uint32_t at = sl; bool done = false;
+                    for (uint32_t p_ = 0; p_ <= bmask && !done; ++p_) {
+                        uint64_t cur = tlo[at];
+                        if (cur == KDF_EMPTY) {
+                            cur = atomicCAS((unsigned long long *)&tlo[at], KDF_EMPTY, key);
+                            if (cur == KDF_EMPTY) { ++claimed; cur = key; }
+                        }
+                        if (cur == key) { atomicAdd(&tcnt[at], 1u); done = true; }
+                        at = (at + 1) & bmask;
+                    }
+                    if (!done) failed = true;
+                }
+            }
+        }
+    }
+    if (failed) sh_fail = 1;
+    __syncthreads();
+    if (sh_fail) { if (tid == 0) s.hv_failed[h] = 1; return; }
+    // stage the private table's pairs: one reservation per workgroup
+    uint32_t mine = 0;
+    for (uint32_t i = tid; i < B; i += 256) mine += tlo[i] != KDF_EMPTY ? 1u : 0u;
+    uint32_t inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if ((int)lane >= o) inc += y; }
+    uint32_t wbase = 0;
+    if (lane == 63) wbase = atomicAdd(&sh_n, inc);
+    wbase = __shfl(wbase, 63);
+    __syncthreads();
+    if (tid == 0) sh_base = atomicAdd(&s.hv_n[h], sh_n);
+    __syncthreads();
+    uint32_t pos = sh_base + wbase + inc - mine;
+    const size_t room = (size_t)KB_HV_SLICES << plan.bucket_bits;
+    uint64_t *ok_ = s.hv_key + (size_t)h * room; uint32_t *oc_ = s.hv_cnt + (size_t)h * room;
+    for (uint32_t i = tid; i < B; i += 256)
+        if (tlo[i] != KDF_EMPTY) { ok_[pos] = tlo[i]; oc_[pos] = tcnt[i]; ++pos; }
+}
+
+__global__ __launch_bounds__(256) void kb_heavy_combine_kernel(KbPlan plan, KbScratch s, KdfTable t, KdfCtl *ctl, int table_nonempty) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (!s.hv_ctr || s.totals[7] == 0 || s.failed_flag[0]) return;
+    const uint32_t nh = min(s.hv_ctr[0], KB_HV_MAX), h = blockIdx.x;
+    if (h >= nh) return;
+    if (h == 0 && threadIdx.x == 0) s.totals[4] = s.hv_ctr[0];     // (statistics: heavy buckets of this pass; the first KB_HV_MAX were split)
+    const uint32_t B = 1u << plan.bucket_bits, bmask = B - 1;
+    uint64_t *tlo = (uint64_t *)smem;
+    uint32_t *tcnt = (uint32_t *)(smem + (size_t)B * 8);
+    __shared__ uint32_t sh_fail, sh_claimed;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t bucket = s.hv_bucket[h];
+    const uint64_t slot0 = bucket << plan.bucket_bits;
+    for (uint32_t i = tid; i < B; i += 256) {
+        tlo[i] = table_nonempty ? t.lo[slot0 + i] : KDF_EMPTY;
+        tcnt[i] = table_nonempty ? t.cnt[slot0 + i] : 0u;
+    }
+    if (tid == 0) { sh_fail = s.hv_failed[h]; sh_claimed = 0; }
+    __syncthreads();
+    const size_t room = (size_t)KB_HV_SLICES << plan.bucket_bits;
+    const uint64_t *ik = s.hv_key + (size_t)h * room; const uint32_t *ic = s.hv_cnt + (size_t)h * room;
+    const uint32_t n = s.hv_n[h];
+    uint32_t claimed = 0; bool failed = false;
+    if (!sh_fail)
+        for (uint32_t i = tid; i < n; i += 256) {
+            const uint64_t key = ik[i]; const uint32_t add = ic[i];
+            uint32_t at = (uint32_t)(kdf_hash(key, 0) >> (64 - plan.log2cap)) & bmask; bool done = false;
+            for (uint32_t p_ = 0; p_ <= bmask && !done; ++p_) {
+                uint64_t cur = tlo[at];
+                if (cur == KDF_EMPTY) {
+                    cur = atomicCAS((unsigned long long *)&tlo[at], KDF_EMPTY, key);
+                    if (cur == KDF_EMPTY) { ++claimed; cur = key; }
+                }
+                if (cur == key) { kb_lds_sat_add(&tcnt[at], add); done = true; }
+                at = (at + 1) & bmask;
+            }
+            if (!done) failed = true;
+        }
+    if (failed) sh_fail = 1;
+    if (claimed) atomicAdd(&sh_claimed, claimed);
+    __syncthreads();
+    if (sh_fail) {                                                 // as kernel C: untouched in HBM, flagged for the replay pass
+        if (tid == 0) { atomicOr(&s.failed[bucket >> 5], 1u << (bucket & 31)); atomicAdd(&s.totals[2], 1ull); }
+        return;                                                    // (kernel C already wrote an empty slice into a lazily cleared table)
+    }
+    for (uint32_t i = tid; i < B; i += 256) { t.lo[slot0 + i] = tlo[i]; t.cnt[slot0 + i] = tcnt[i]; }
+    if (tid == 0 && sh_claimed) atomicAdd(&ctl->distinct[(bucket % KDF_SHARDS) * 16], (unsigned long long)sh_claimed);
+}
+

@@ -451,6 +451,8 @@ struct kdf_engine {
     void *up_buf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; size_t up_bytes[2][2] = {{0, 0}, {0, 0}};
     uint64_t up_n[2] = {0, 0}; bool up_valid[2] = {false, false};
     hipStream_t copy_stream = nullptr; hipEvent_t up_done[2] = {nullptr, nullptr}, use_done[2] = {nullptr, nullptr};
+    uint64_t stat_heavy_buckets = 0;
+    void *kb_heavy = nullptr;                        // heavy buckets of skewed binned passes (kdf_binned.h kb_heavy_slice_kernel)
     void *merge_buf = nullptr; size_t merge_bytes = 0;   // kdf_merge.h: block counts / offsets of the ordered dump, bucket ranges of a merge
     uint32_t merge_flag_host = 0;
     int last_merge_path = 0;                         // 0 none yet, 1 LDS bucket merge launched, 2 plain atomic insert
@@ -760,10 +762,20 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
         HIPCHK(h, hipMalloc((void **)&h->kb_small, (size_t)(4 * (nb1 + 1) + 16) * 8));
         HIPCHK(h, hipHostMalloc((void **)&h->kb_totals_host, 128));
     }
+    if (KW == 1 && !h->kb_heavy) {                             // heavy buckets of skewed passes (kb_heavy_slice_kernel): ~100 MB, once
+        const size_t pairs = (size_t)KB_HV_MAX * KB_HV_SLICES << 12;
+        HIPCHK(h, hipMalloc((void **)&h->kb_heavy, pairs * 12 + (4 + 3 * KB_HV_MAX) * 4));
+        HIPCHK(h, hipMemsetAsync((char *)h->kb_heavy + pairs * 12, 0, (4 + 3 * KB_HV_MAX) * 4, h->stream));
+    }
     KbScratch s{};
     s.hist1 = h->kb_small; s.bin_start = s.hist1 + (nb1 + 1);
     s.chunk_first = s.bin_start + 2 * (nb1 + 1); s.totals = s.chunk_first + (nb1 + 1);
     s.failed_flag = (unsigned int *)(s.totals + 8);
+    if (KW == 1 && h->kb_heavy) {
+        const size_t pairs = (size_t)KB_HV_MAX * KB_HV_SLICES << 12;
+        s.hv_key = (uint64_t *)h->kb_heavy; s.hv_cnt = (uint32_t *)(s.hv_key + pairs);
+        s.hv_ctr = s.hv_cnt + pairs; s.hv_bucket = s.hv_ctr + 4; s.hv_n = s.hv_bucket + KB_HV_MAX; s.hv_failed = s.hv_n + KB_HV_MAX;
+    }
     const size_t lds_b = (size_t)CHUNK * 8 * KW + (size_t)(2 * KB_F + 32) * 4 + 16;
     const size_t lds_c = ((size_t)8 * KW + 4) * ((size_t)1 << plan.bucket_bits) + (2 + 32 + KB_C_RUNS) * 4 + (size_t)KB_C_RUNS * 8
                          + (KW == 2 ? (size_t)KB_C_RUNS * 4 : 0);                           // wide: run_hi
@@ -912,6 +924,12 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     else
         if (var1) KB_LVS(KB_MODE_INSERT);
         else hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_INSERT, 0>), dim3((unsigned)nb_table), dim3(KB_C_CT(KW)), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty);
+    if (KW == 1 && !filtered && var1 && s.hv_ctr && plan.bucket_bits == 12) {
+        // the buckets the skewed-pass instantiation left aside (none in an ordinary pass: both kernels return at once)
+        const size_t lds_h = (size_t)12 << plan.bucket_bits;
+        hipLaunchKernelGGL(kb_heavy_slice_kernel, dim3(KB_HV_SLICES, KB_HV_MAX), dim3(256), lds_h, h->stream, plan, s);
+        hipLaunchKernelGGL(kb_heavy_combine_kernel, dim3(KB_HV_MAX), dim3(256), lds_h, h->stream, plan, s, h->t, h->ctl, nonempty);
+    }
     HIPCHK(h, hipGetLastError());
     if (h->prof) {
         stamp();                                               // end of C
@@ -926,6 +944,7 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     h->stat_binned_passes++;
     h->lazy_empty = false;
     for (int i = 0; i < 6; ++i) h->stat_dbg[i] = h->kb_totals_host[9 + i];
+    h->stat_heavy_buckets += h->kb_totals_host[4];
     if (((unsigned int *)(h->kb_totals_host + 8))[0] && cells) {
         // a cell overflowed: B and C did nothing (they saw the flag).  The windows A1 counted are taken back and the
         // pass is redone with the exact layout; this engine stays on it (its input is skewed).
@@ -1518,6 +1537,7 @@ void kdf_destroy(kdf_engine *h) {
     for (int i = 0; i < 16; ++i) if (h->sk_buf[i]) (void)hipFree(h->sk_buf[i]);
     for (int i = 0; i < 8; ++i) if (h->kp_buf[i]) (void)hipFree(h->kp_buf[i]);
     if (h->merge_buf) (void)hipFree(h->merge_buf);
+    if (h->kb_heavy) (void)hipFree(h->kb_heavy);
     for (int sl = 0; sl < 2; ++sl) {
         for (int j = 0; j < 2; ++j) if (h->up_buf[sl][j]) (void)hipFree(h->up_buf[sl][j]);
         if (h->up_done[sl]) (void)hipEventDestroy(h->up_done[sl]);
@@ -2332,6 +2352,7 @@ int kdf_get_stat(kdf_engine *h, const char *name, int64_t *value) {
     else if (n == "layout") *value = h->t.sk ? (h->t.sk_assign ? 2 : 1) : 0;
     else if (n == "last_count_path") *value = h->last_path;
     else if (n == "last_merge_path") *value = h->last_merge_path;
+    else if (n == "heavy_buckets") *value = (int64_t)h->stat_heavy_buckets;
     else if (n == "hash_shift") *value = h->opt_hash_shift;
     else if (n == "ovf_log2cap") *value = h->t.ovf_lo ? (int64_t)h->t.ovf_log2cap : 0;
     else if (n == "log2cap") *value = h->t.log2cap;

@@ -1,9 +1,8 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests/test_gpu_parity_basic.py tests/test_gpu_scale.py tests/test_gpu_fuzz.py tests/test_gpu_superkmer.py tests/test_gpu_configs.py -x -q 2>&1 | tail -3 && \
-timeout -k 10 300 python bench.py --steps 20 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['stage_avg_ms'])" && \
-timeout -k 10 300 python bench.py --k 63 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['stage_avg_ms'])" && \
+timeout -k 10 900 python -m pytest tests/test_gpu_parity_basic.py -x -q 2>&1 | tail -5 && \
 SKEW_PATHS=1 timeout -k 10 600 python scratch/skew_probe.py 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
-    d = json.loads(l); print(d['genome'], d['wall_ms'], d['stage_ms'])"
+    d = json.loads(l); print(d['genome'], d['wall_ms'], d['stage_ms'], d['distinct'], d['max_count'])" && \
+timeout -k 10 600 python scratch/skew_check.py 2>&1 | grep -v amdgpu | tail -3 | cut -c1-150

@@ -43,7 +43,7 @@ for gname, g in genomes.items():
         row = {"genome": gname, "path": pname, "wall_ms": round(best, 2), "Gkmer_per_s": round(windows / best / 1e6, 1), "windows": windows,
                "distinct": distinct, "slots": cap, "kmers_ge1000": int(len(lo)), "max_count": int(cnt.max()) if len(cnt) else 0,
                "stage_ms": {n: round(x, 2) for n, x in zip(names, stage_ms)}}
-        for s in ("sk_spills", "sk_failed_buckets", "sk_passes", "ovf_log2cap", "replayed_buckets", "sk_fallbacks"):
+        for s in ("heavy_buckets", "sk_spills", "sk_failed_buckets", "sk_passes", "ovf_log2cap", "replayed_buckets", "sk_fallbacks"):
             try: row[s] = e.get_stat(s)
             except Exception: pass
         print(json.dumps(row), flush=True)

@@ -386,3 +386,42 @@ def test_binned_cells_variant_and_its_overflow_fallback(oracle, k):
         l3, h3, c3 = t3.export_ge(0)
         glo, ghi, gcnt = e.export_ge(0)
         np.testing.assert_array_equal(glo, l3); np.testing.assert_array_equal(gcnt, c3)
+
+
+def test_heavy_buckets_are_split_and_stay_exact(oracle):
+    """A skewed pass (one coarse bin far above its share) runs the second instantiation of kernel C; buckets whose runs
+    hold more than 65 536 entries are left to kb_heavy_slice_kernel / kb_heavy_combine_kernel (32 workgroups per bucket,
+    private LDS tables, transactional fold).  Homopolymer and microsatellite reads by the hundred thousand, in two
+    batches (the second into the live table), against the oracle and against the direct path."""
+    import torch
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    rng = np.random.default_rng(12)
+    k = 31
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    fl = lambda n: acgt[rng.integers(0, 4, n)].tobytes().decode()
+    heavy = []
+    for _ in range(60_000):
+        heavy.append(fl(int(rng.integers(5, 40))) + "A" * int(rng.integers(40, 100)) + fl(int(rng.integers(5, 30))))
+    for _ in range(30_000):
+        heavy.append(fl(10) + "CA" * int(rng.integers(25, 50)) + fl(12))
+    for _ in range(20_000):
+        heavy.append("GAA" * int(rng.integers(15, 35)) + fl(20))
+    reads = heavy + rand_reads(rng, 60_000, 100, 151)
+    rng.shuffle(reads)
+    lo, hi, cnt = oracle.OracleTable(k, 1 << 12).count_reads(reads, threads=8).export_ge(0)
+    assert int(cnt.max()) > 1_000_000
+    st = ReadStream.from_strings(reads)
+    half = len(reads) // 2
+    for hint, batches in ((1 << 22, 1), (1 << 22, 2), (1 << 16, 1)):
+        with KmerEngine(k, capacity_hint=hint) as e:
+            e.set_option("force_path", 2)
+            if batches == 1:
+                e.count(st)
+            else:
+                e.count(ReadStream.from_strings(reads[:half])); e.count(ReadStream.from_strings(reads[half:]))
+            glo, ghi, gcnt = e.export_ge(0)
+            np.testing.assert_array_equal(glo, lo); np.testing.assert_array_equal(gcnt, cnt)
+            assert e.stats()[2] == oracle.count_windows(reads, k)
+            np.testing.assert_array_equal(e.query(lo[::7], None), cnt[::7])
+            if hint == 1 << 22 and batches == 1:
+                assert e.get_stat("heavy_buckets") > 0, "the skewed instantiation did not split any bucket: the test does not reach the code"
