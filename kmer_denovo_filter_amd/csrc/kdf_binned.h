@@ -106,9 +106,13 @@ struct KbScratch {
     uint64_t *hv_key;               // [KB_HV_MAX][KB_HV_SLICES << 12]
     uint32_t *hv_cnt;
 };
+#ifndef KB_HV_MAX
 #define KB_HV_MAX    64u                             // heavy buckets split per pass (further ones are processed the ordinary way)
+#endif
 #define KB_HV_SLICES 32u                             // workgroups that share one heavy bucket's runs
+#ifndef KB_C_HEAVY
 #define KB_C_HEAVY   65536u                          // entries (first 256 runs) from which a bucket counts as heavy: ~7x a bucket's share at bench load
+#endif
 #define KB_GROUP 32                                  // pool chunks per fine-sort group
 #define KB_PCH(KW) (KbCfg<KW>::CHUNK / KB_GROUP)     // entries per pool chunk: 4 KB for either key width
 #define KB_NOCHUNK 0xFFFFFFFFu
