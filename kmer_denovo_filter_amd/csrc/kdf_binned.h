@@ -812,8 +812,9 @@ __device__ __forceinline__ void kb_lds_sat_add(uint32_t *p, uint32_t add) {
 // the SAME slot -- a key of enormous multiplicity: a homopolymer k-mer took 1.4 % of all windows of a repeat-rich genome, all
 // of them in one workgroup -- one lane adds the lot instead of 64 adds serialising on one LDS address (kernel C 14.6 -> 10.2
 // ms there, pass 24.8 -> 20.4 ms).  The test costs every wave ~8 instructions per key (+3 % on the kernel for a uniform
-// genome), so it lives in its own instantiation of the kernel (VAR 2), which runs only when the coarse histogram is skewed
-// (kb_scan1_kernel sets totals[7]); both instantiations are launched, the one that does not apply returns at once.
+// genome), so it lives in its own instantiation of the kernel (VAR 2).  kb_scan1_kernel reports a skewed coarse histogram
+// (totals[7]) and the host launches VAR 2 for the passes that FOLLOW a skewed one (a sample is many passes; launching both
+// instantiations and letting the device pick cost 0.08 ms per pass for 131 K workgroups that return at once).
 template <bool AGG>
 __device__ __forceinline__ void kb_count_hits(uint32_t *tcnt, uint32_t sl, bool hit) {
     if constexpr (AGG) {
@@ -937,9 +938,7 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
     // (f, f + 1 of one coarse bin) read neighbouring runs of the same chunks -- they share the cache line at every run
     // boundary and the lines of the offset table -- so an XCD takes a contiguous eighth of the buckets, in order.
     if (s.failed_flag[0]) return;                              // the partition is not usable (a cell overflowed / the stream changed): the host knows
-    if constexpr (VAR >= 1 && MODE != KB_MODE_REPLAY) {
-        if ((VAR == 2) != (s.totals[7] != 0)) return;          // the other instantiation handles this pass (kb_count_hits)
-    }
+
     if (plan.cells && MODE != KB_MODE_REPLAY && blockIdx.x == 0 && threadIdx.x == 0 && s.totals[5])
         atomicAdd(&ctl->windows[0], s.totals[5]);              // the valid windows the cell scatter counted
     const uint32_t nbk = gridDim.x;
@@ -1388,7 +1387,7 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
 __global__ __launch_bounds__(256) void kb_heavy_slice_kernel(KbPlan plan, KbScratch s) {
     constexpr int CHUNK = KbCfg<1>::CHUNK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (!s.hv_ctr || s.totals[7] == 0 || s.failed_flag[0]) return;
+    if (!s.hv_ctr || s.failed_flag[0]) return;
     const uint32_t nh = min(s.hv_ctr[0], KB_HV_MAX), h = blockIdx.y, slice = blockIdx.x;
     if (h >= nh) return;
     const uint32_t B = 1u << plan.bucket_bits, bmask = B - 1;
@@ -1461,7 +1460,7 @@ __global__ __launch_bounds__(256) void kb_heavy_slice_kernel(KbPlan plan, KbScra
 
 __global__ __launch_bounds__(256) void kb_heavy_combine_kernel(KbPlan plan, KbScratch s, KdfTable t, KdfCtl *ctl, int table_nonempty) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (!s.hv_ctr || s.totals[7] == 0 || s.failed_flag[0]) return;
+    if (!s.hv_ctr || s.failed_flag[0]) return;
     const uint32_t nh = min(s.hv_ctr[0], KB_HV_MAX), h = blockIdx.x;
     if (h >= nh) return;
     if (h == 0 && threadIdx.x == 0) s.totals[4] = s.hv_ctr[0];     // (statistics: heavy buckets of this pass; the first KB_HV_MAX were split)

@@ -452,6 +452,7 @@ struct kdf_engine {
     uint64_t up_n[2] = {0, 0}; bool up_valid[2] = {false, false};
     hipStream_t copy_stream = nullptr; hipEvent_t up_done[2] = {nullptr, nullptr}, use_done[2] = {nullptr, nullptr};
     uint64_t stat_heavy_buckets = 0;
+    bool kb_skewed = false;                          // the last binned pass saw a skewed coarse histogram (kdf_binned.h kb_count_hits)
     void *kb_heavy = nullptr;                        // heavy buckets of skewed binned passes (kdf_binned.h kb_heavy_slice_kernel)
     void *merge_buf = nullptr; size_t merge_bytes = 0;   // kdf_merge.h: block counts / offsets of the ordered dump, bucket ranges of a merge
     uint32_t merge_flag_host = 0;
@@ -916,16 +917,18 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     // narrow keys: lookahead + wave-queue variant of kernel C (debug flag 8 selects the plain loop, for A/B runs)
     const bool var1 = !(h->opt_debug_flags & 8);
     const int nonempty = h->lazy_empty ? 0 : 1;   // 0: kernel C rewrites every bucket (this IS the clear)
-    if (filtered)
+    // VAR 2 = VAR 1 + wave-aggregated count adds + heavy-bucket listing: for the passes that follow a skewed one (kdf_binned.h kb_count_hits)
+    const bool skew_var = h->kb_skewed && !cells && !h->opt_binned_pool;
 #define KB_LV(M, V) hipLaunchKernelGGL((kb_bucket_kernel<KW, M, V>), dim3((unsigned)nb_table), dim3(KB_C_CT(KW)), lds_c + KB_C_QEXTRA(V, KW), h->stream, plan, s, h->t, h->ctl, nonempty)
-#define KB_LVS(M) do { KB_LV(M, 1); KB_LV(M, 2); } while (0)      /* VAR 2 = VAR 1 + aggregated count adds; the device picks one (totals[7]) */
+#define KB_LVS(M) do { if (skew_var) KB_LV(M, 2); else KB_LV(M, 1); } while (0)
+    if (filtered)
         if (var1) KB_LVS(KB_MODE_FILTERED);
         else hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_FILTERED, 0>), dim3((unsigned)nb_table), dim3(KB_C_CT(KW)), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty);
     else
         if (var1) KB_LVS(KB_MODE_INSERT);
         else hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_INSERT, 0>), dim3((unsigned)nb_table), dim3(KB_C_CT(KW)), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty);
-    if (KW == 1 && !filtered && var1 && s.hv_ctr && plan.bucket_bits == 12) {
-        // the buckets the skewed-pass instantiation left aside (none in an ordinary pass: both kernels return at once)
+    if (KW == 1 && !filtered && var1 && skew_var && s.hv_ctr && plan.bucket_bits == 12) {
+        // the buckets the skewed-pass instantiation left aside
         const size_t lds_h = (size_t)12 << plan.bucket_bits;
         hipLaunchKernelGGL(kb_heavy_slice_kernel, dim3(KB_HV_SLICES, KB_HV_MAX), dim3(256), lds_h, h->stream, plan, s);
         hipLaunchKernelGGL(kb_heavy_combine_kernel, dim3(KB_HV_MAX), dim3(256), lds_h, h->stream, plan, s, h->t, h->ctl, nonempty);
@@ -945,6 +948,7 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     h->lazy_empty = false;
     for (int i = 0; i < 6; ++i) h->stat_dbg[i] = h->kb_totals_host[9 + i];
     h->stat_heavy_buckets += h->kb_totals_host[4];
+    h->kb_skewed = !cells && !h->opt_binned_pool && h->kb_totals_host[7] != 0;      // what the NEXT pass of this engine is launched for
     if (((unsigned int *)(h->kb_totals_host + 8))[0] && cells) {
         // a cell overflowed: B and C did nothing (they saw the flag).  The windows A1 counted are taken back and the
         // pass is redone with the exact layout; this engine stays on it (its input is skewed).

@@ -389,9 +389,9 @@ def test_binned_cells_variant_and_its_overflow_fallback(oracle, k):
 
 
 def test_heavy_buckets_are_split_and_stay_exact(oracle):
-    """A skewed pass (one coarse bin far above its share) runs the second instantiation of kernel C; buckets whose runs
-    hold more than 65 536 entries are left to kb_heavy_slice_kernel / kb_heavy_combine_kernel (32 workgroups per bucket,
-    private LDS tables, transactional fold).  Homopolymer and microsatellite reads by the hundred thousand, in two
+    """The passes that follow a skewed one (one coarse bin far above its share) run the second instantiation of kernel C;
+    buckets whose runs hold more than 65 536 entries are left to kb_heavy_slice_kernel / kb_heavy_combine_kernel (32
+    workgroups per bucket, private LDS tables, transactional fold).  Homopolymer and microsatellite reads by the hundred thousand, in two
     batches (the second into the live table), against the oracle and against the direct path."""
     import torch
     from kmer_denovo_filter_amd import KmerEngine, ReadStream
@@ -415,6 +415,7 @@ def test_heavy_buckets_are_split_and_stay_exact(oracle):
     for hint, batches in ((1 << 22, 1), (1 << 22, 2), (1 << 16, 1)):
         with KmerEngine(k, capacity_hint=hint) as e:
             e.set_option("force_path", 2)
+            e.count(ReadStream.from_strings(reads[:half])); e.clear()           # the engine has now seen a skewed pass
             if batches == 1:
                 e.count(st)
             else:
