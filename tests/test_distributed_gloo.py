@@ -150,9 +150,9 @@ def _worker(rank, world, port, k, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k", [21, 41])
-def test_owner_partitioned_count_and_sharded_filter_world2(oracle, k):
-    world = 2
+@pytest.mark.parametrize("k,world", [(21, 2), (41, 2), (31, 3)])
+def test_owner_partitioned_count_and_sharded_filter_world2(oracle, k, world):
+    """(world 3: owner ranges that are not a power-of-two split of the hash space, a read shard of a different size per rank)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
