@@ -433,6 +433,7 @@ struct kdf_engine {
     size_t kb_bytes[6] = {0, 0, 0, 0, 0, 0};
     uint32_t opt_key_parts = 0, opt_key_part = 0;    // count only one slice of the key space (KdfTable::key_parts)
     uint64_t opt_binned_min_positions = 1ull << 22;  // smaller batches use the direct global-table kernels
+    uint64_t opt_binned_bytes_per_position = 70;     // insert passes go binned only from table_bytes / 70 positions on (use_binned)
     uint64_t opt_binned_max_positions = 1ull << 31;  // longer streams are walked in several binned passes: a pass must add
                                                      // < 2^32 to any slot (kernel C saturates by comparing with the HBM count)
     uint32_t opt_binned_filtered_min_log2cap = 23;   // count --if goes binned from 2^23 slots (measured crossover)
@@ -1377,6 +1378,17 @@ static bool use_binned(const kdf_engine *h, uint64_t n_bases, bool filtered) {
     if (h->opt_force_path == 2) return true;
     if (n_bases < h->opt_binned_min_positions) return false;
     if (filtered && h->t.log2cap < h->opt_binned_filtered_min_log2cap) return false;
+    // A binned pass reads and rewrites EVERY bucket of the table (0.5 ms per GB), whatever the batch holds; the direct
+    // kernels cost 0.056 ms per million positions whatever the table.  A streamed sample is many batches into one big
+    // table (2^26 positions each from _stream_bam): measured 52 ms binned against 3.5 ms direct per batch at 103 GB.
+    // Crossover (scratch/bigtable_probe.py): ~14 M positions per GB of table.
+    if (!filtered) {
+        // (a table that was only `clear`ed: the binned pass would also be its clear, the direct path pays a memset first --
+        // 0.2 ms per GB -- which moves the crossover to ~8.6 M positions per GB)
+        const uint64_t table_bytes = h->cap * (uint64_t)(8 * h->kw + 4);
+        const uint64_t per = h->lazy_empty ? h->opt_binned_bytes_per_position * 5 / 3 : h->opt_binned_bytes_per_position;
+        if (n_bases * per < table_bytes) return false;
+    }
     return true;
 }
 
@@ -2313,6 +2325,7 @@ int kdf_set_option(kdf_engine *h, const char *name, int64_t value) {
         h->opt_key_parts = parts; h->opt_key_part = n == "key_parts" ? 0 : part;
     }
     else if (n == "binned_min_positions") h->opt_binned_min_positions = (uint64_t)value;
+    else if (n == "binned_bytes_per_position") h->opt_binned_bytes_per_position = (uint64_t)value;
     else if (n == "binned_max_positions") {
         if (value < KDF_TILE || value > (1ll << 31)) return fail(h, KDF_ERR_INVALID, "binned_max_positions must be in [64, 2^31]");
         h->opt_binned_max_positions = (uint64_t)value / KDF_TILE * KDF_TILE;      // passes start on tile boundaries
