@@ -1382,7 +1382,8 @@ static bool use_binned(const kdf_engine *h, uint64_t n_bases, bool filtered) {
     // kernels cost 0.056 ms per million positions whatever the table.  A streamed sample is many batches into one big
     // table (2^26 positions each from _stream_bam): measured 52 ms binned against 3.5 ms direct per batch at 103 GB.
     // Crossover (scratch/bigtable_probe.py): ~14 M positions per GB of table.
-    if (!filtered) {
+    {
+        // (count --if through the binned path reads every bucket and rewrites its counts just the same.)
         // (a table that was only `clear`ed: the binned pass would also be its clear, the direct path pays a memset first --
         // 0.2 ms per GB -- which moves the crossover to ~8.6 M positions per GB)
         const uint64_t table_bytes = h->cap * (uint64_t)(8 * h->kw + 4);
