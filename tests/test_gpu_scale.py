@@ -220,3 +220,29 @@ def test_owner_partitioned_count_two_processes(k):
         assert sum(r[1][i] for r in res) == exp[i], (i, [r[1] for r in res], exp)
     assert all(r[1][3] == exp[2] for r in res)                                  # merge() returns the global count on every rank
     assert sum(r[3] for r in res) == exp[0] and all(r[3] > 0 for r in res)     # ownership is exclusive and shared out
+
+
+def test_path_choice_follows_batch_and_table_size():
+    """A binned pass rewrites every bucket of the table whatever the batch holds, so a small batch into a big table takes
+    the direct kernels and a big batch the binned pipeline (csrc/kdf_engine.hip use_binned: ~14 M positions per GB); the
+    tables they build are the same."""
+    import torch
+    from kmer_denovo_filter_amd import KmerEngine
+    small, big = _dev_stream(100_000, seed=1), _dev_stream(2_000_000, seed=2)        # 15 M / 302 M positions
+    dumps = {}
+    for name, force in (("auto", 0), ("direct", 1), ("binned", 2)):
+        with KmerEngine(31, capacity_hint=1 << 27) as e:                          # 2^28 slots = 3.2 GB: crossover ~46 M positions
+            e.set_option("force_path", force)
+            taken = []
+            for ds in (small, big, small):
+                e.count_dev(ds.packed.data_ptr(), ds.invalid.data_ptr(), ds.n_bases); e.synchronize()
+                taken.append(e.last_count_path())
+            if name == "auto":
+                assert taken == ["direct", "binned", "direct"], taken
+            _, distinct, windows = e.stats()
+            lo = torch.empty(distinct, dtype=torch.int64, device="cuda:0"); cnt = torch.empty(distinct, dtype=torch.int32, device="cuda:0")
+            n = e.export_ge_dev(0, lo.data_ptr(), None, cnt.data_ptr(), distinct, sorted_=True); e.synchronize()
+            dumps[name] = (lo[:n], cnt[:n], windows)
+    for name in ("direct", "binned"):
+        assert dumps[name][2] == dumps["auto"][2]
+        assert torch.equal(dumps[name][0], dumps["auto"][0]) and torch.equal(dumps[name][1], dumps["auto"][1])
