@@ -923,7 +923,9 @@ __device__ __forceinline__ void kb_probe_wide_wave(uint64_t *tlo, uint64_t *thi,
 // that need more go to a wave-private queue in LDS (ballot + mbcnt, no atomics, no
 // barrier) and are probed densely, one per lane, after the batch.  Measured on the
 // bench pass: kernel C 7.6 -> 6.5 ms at k = 31, 16.0 -> 12.7 ms at k = 63.
+#ifndef KB_C_LA
 #define KB_C_LA    2                   // VAR 1: slots of the probe sequence read up front
+#endif
 #define KB_C_QCAPK(KW) (((KW) == 2 ? KB_C_WQ_W : 128) * (KB_C_CT(KW) / 64))   // VAR 1: queue entries per workgroup
 #define KB_C_QEXTRA(VAR, KW) ((VAR) ? (KB_C_QCAPK(KW) * ((KW) == 2 ? 18 : 10) + 16 + (KB_C_RUNS + 4) * 4) : 0)   // LDS bytes VAR 1 adds
 template <int KW, int MODE, int VAR>
