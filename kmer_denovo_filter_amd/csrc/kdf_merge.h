@@ -1,5 +1,5 @@
 // kdf_merge.h -- the two ends of the multi-GPU merge of per-rank counts (`jellyfish merge` of partial indexes,
-// reference kmer_denovo_filter/core/jellyfish_wrappers.py:335-366, done in HBM across ranks; DESIGN.md section 6).
+// reference kmer_denovo_filter/core/jellyfish_wrappers.py:335-366, done in HBM across ranks; DESIGN.md section 5).
 //
 // SENDER  (kdf_export_parts_dev): the hash-layout table is dumped in HASH ORDER -- exactly grouped by the top
 //   P = log2cap - 12 + KM_SUB_BITS bits of the key's hash -- into one contiguous range per owner rank.  Two reads of
