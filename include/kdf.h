@@ -89,12 +89,17 @@ int kdf_stats(kdf_engine *h, uint64_t *capacity, uint64_t *distinct, uint64_t *w
  *            the same stream; insert mode only; 0/1 = everything); "binned_max_positions" (positions per
  *            binned pass, <= 2^31: longer streams take several passes); "binned_filtered_min_log2cap"
  *            "sk_auto" (1: big batches of narrow keys from k = sk_min_k on take the super-k-mer pipeline by
- *            themselves), "sk_balance", "binned_pool", "sieve_bits" (bits per filter key; 0 = by size);
- *            force_path 4 = count --if through the sieve only
- *   stats    "binned_passes", "replayed_buckets", "log2cap", "bucket_bits", "layout" (0 hash, 1 minimizer-bucketed,
- *            2 with the balanced assignment table), "binned_pool",
- *            "last_count_path" (0 direct / 1 binned / 2 super-k-mer), "sk_passes", "sk_spills",
- *            "sk_failed_buckets", "sk_fallbacks", "ovf_log2cap" */
+ *            themselves), "sk_balance", "binned_pool", "binned_cells", "sieve_bits" (bits per filter key; 0 = by size);
+ *            force_path 4 = count --if through the sieve only; "binned_bytes_per_position" (a count call goes
+ *            binned only when positions x this >= table bytes: a binned pass rewrites the whole table; default 70);
+ *            "hash_shift" (0..8, empty table only: the home slot ignores that many top hash bits -- the table of
+ *            an OWNER rank of the multi-GPU merge, see kdf_add_pairs_multi_dev; such an engine counts through the
+ *            direct kernels only); "merge_min_pairs" (below this many pairs kdf_add_pairs* skips the bucket merge)
+ *   stats    "binned_passes", "replayed_buckets", "heavy_buckets" (buckets of skewed passes that were shared by
+ *            several workgroups), "log2cap", "bucket_bits", "layout" (0 hash, 1 minimizer-bucketed,
+ *            2 with the balanced assignment table), "binned_pool", "binned_cells", "hash_shift",
+ *            "last_count_path" (0 direct / 1 binned / 2 super-k-mer / 3 sieve), "last_merge_path" (1 LDS bucket
+ *            merge, 2 global atomics), "sk_passes", "sk_spills", "sk_failed_buckets", "sk_fallbacks", "ovf_log2cap" */
 int kdf_set_option(kdf_engine *h, const char *name, int64_t value);
 /* Free / total HBM of a device (hipMemGetInfo): the child-count mirror sizes "key_parts" with it. */
 int kdf_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
