@@ -919,7 +919,7 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     const bool var1 = !(h->opt_debug_flags & 8);
     const int nonempty = h->lazy_empty ? 0 : 1;   // 0: kernel C rewrites every bucket (this IS the clear)
     // VAR 2 = VAR 1 + wave-aggregated count adds + heavy-bucket listing: for the passes that follow a skewed one (kdf_binned.h kb_count_hits)
-    const bool skew_var = h->kb_skewed && !cells && !h->opt_binned_pool;
+    const bool skew_var = (h->kb_skewed || (h->opt_debug_flags & 4096)) && !cells && !h->opt_binned_pool;   // (debug flag 4096 forces it: fuzzing)
 #define KB_LV(M, V) hipLaunchKernelGGL((kb_bucket_kernel<KW, M, V>), dim3((unsigned)nb_table), dim3(KB_C_CT(KW)), lds_c + KB_C_QEXTRA(V, KW), h->stream, plan, s, h->t, h->ctl, nonempty)
 #define KB_LVS(M) do { if (skew_var) KB_LV(M, 2); else KB_LV(M, 1); } while (0)
     if (filtered)

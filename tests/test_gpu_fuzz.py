@@ -79,8 +79,10 @@ def round2_case(O, rng, scale, tag0):
     tag = f"{tag0} k={k} reads={len(reads)} path={path} cells={cells} pool={pool} hshift={hshift} hint={hint} maxpos={maxpos}"
     lo, hi, cnt = O.OracleTable(k, 1 << 12).count_reads(reads).export_ge(0)
 
+    skewvar = 4096 if rng.random() < 0.5 else 0              # kernel C's skew instantiation (wave-aggregated count adds), forced
+
     def opts(e, p=path):
-        e.set_option("force_path", p); e.set_option("binned_max_positions", maxpos)
+        e.set_option("force_path", p); e.set_option("binned_max_positions", maxpos); e.set_option("debug_flags", skewvar)
         e.set_option("binned_cells", cells); e.set_option("binned_pool", pool)
 
     with KmerEngine(k, capacity_hint=hint) as e:
