@@ -237,6 +237,20 @@ __global__ __launch_bounds__(KDF_EXPORT1_THREADS) void kdf_export1_kernel(KdfTab
     const uint64_t wave = (uint64_t)blockIdx.x * (KDF_EXPORT1_THREADS / 64) + wv;
     const uint64_t first = wave * (ROWS * 64);
     uint64_t lo[ROWS], hi[KW == 2 ? ROWS : 1]; uint32_t c[ROWS];
+    unsigned long long kb[ROWS]; uint32_t tot = 0;
+    if (KW == 1 && min_count >= 1) {
+        // a count > 0 implies an occupied slot: read the counts first and the keys only where they are kept (a `dump -L 3`
+        // keeps a fifth of the slots: the memory system fetches the key sectors that hold at least one kept slot)
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { const uint64_t i = first + (uint64_t)r * 64 + lane; c[r] = i < cap ? t.cnt[i] : 0u; }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint64_t i = first + (uint64_t)r * 64 + lane;
+            const bool keep = c[r] >= min_count;
+            lo[r] = keep ? t.lo[i] : KDF_EMPTY;
+            kb[r] = __ballot(keep); tot += (uint32_t)__popcll(kb[r]);
+        }
+    } else {
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const uint64_t i = first + (uint64_t)r * 64 + lane;
@@ -245,11 +259,11 @@ __global__ __launch_bounds__(KDF_EXPORT1_THREADS) void kdf_export1_kernel(KdfTab
         lo[r] = in ? t.lo[i] : KDF_EMPTY;
         if constexpr (KW == 2) hi[r] = in ? t.hi[i] : KDF_EMPTY;
     }
-    unsigned long long kb[ROWS]; uint32_t tot = 0;
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const bool occ = KW == 1 ? (lo[r] != KDF_EMPTY) : (hi[r] != KDF_EMPTY);
         kb[r] = __ballot(c[r] >= min_count && occ); tot += (uint32_t)__popcll(kb[r]);
+    }
     }
     if (lane == 0) wtot[wv] = tot;
     __syncthreads();
