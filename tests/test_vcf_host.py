@@ -65,3 +65,48 @@ def test_parse_vcf_and_annotation(tmp_path):
     ann = annotate_variants(v[:1], vk, {"AAAC": 5, "CCCC": 2})
     assert ann["chr1:100:A:T"] == {"dku": 1, "dkt": 2, "dka": 1, "dku_dkt": 0.5, "dka_dkt": 0.5, "max_pkc": 5,
                                    "avg_pkc": 3.5, "min_pkc": 2, "max_pkc_alt": 5, "avg_pkc_alt": 5, "min_pkc_alt": 5}
+
+
+def test_records_over_positions_matches_the_per_record_loop():
+    """The vectorised matching of a batch's records against sorted variant positions (CIGAR reference spans +
+    searchsorted per chromosome) against the obvious loop -- pysam's `fetch(chrom, pos, pos + 1)` semantics as the
+    reference uses them (vcf/pipeline.py:619-726): a record is taken iff start <= pos < reference_end."""
+    import bisect
+    import os
+    import numpy as np
+    from kmer_denovo_filter_amd.core.bam_scanner import reference_end
+    from kmer_denovo_filter_amd.reads import bam_reader
+    from kmer_denovo_filter_amd.vcf.pipeline import _parse_vcf_variants, _records_over_positions
+    giab = os.path.join(os.path.dirname(__file__), "golden", "giab")
+    variants = _parse_vcf_variants(os.path.join(giab, "candidates.vcf.gz"), proband_id="HG002")
+    by_chrom = {}
+    for v in variants:
+        by_chrom.setdefault(v["chrom"], set()).add(v["pos"])
+    rng = np.random.default_rng(4)
+    for c in list(by_chrom):                                    # plus random positions, so that most batches have hits and misses
+        by_chrom[c] |= set(int(x) for x in rng.integers(min(by_chrom[c]) - 2000, max(by_chrom[c]) + 2000, 40))
+    vpos = {c: np.asarray(sorted(p), dtype=np.int64) for c, p in by_chrom.items()}
+    rd = bam_reader(os.path.join(giab, "HG002_child.bam"), flag_off=0, collapse=False, max_bases=1 << 16, threads=2, want_aux=True)
+    refs = rd.references()
+    n_hit = n_all = 0
+    with rd:
+        for batch in rd:
+            n = batch.n_reads
+            elig = (np.asarray(batch.flags[:n]) & 0x4) == 0
+            for empty_one in (False, True):
+                keep, first = _records_over_positions(batch, refs, vpos, elig, empty_span_is_one=empty_one)
+                exp_keep, exp_first = [], []
+                for i in range(n):
+                    rid = int(batch.ref_ids[i])
+                    if not elig[i] or rid < 0 or refs[rid] not in vpos:
+                        continue
+                    start = int(batch.positions[i]); end = reference_end(start, batch.cigartuples(i))
+                    if empty_one and end <= start:
+                        end = start + 1
+                    pl = vpos[refs[rid]]
+                    j = bisect.bisect_left(pl.tolist(), start)
+                    if j < len(pl) and pl[j] < end:
+                        exp_keep.append(i); exp_first.append(j)
+                assert keep.tolist() == exp_keep and first.tolist() == exp_first
+            n_hit += len(keep); n_all += n
+    assert 0 < n_hit < n_all
