@@ -64,7 +64,7 @@ def parse_args(argv=None):
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--genome", type=int, default=100_000_000)
-    ap.add_argument("--path", choices=["auto", "direct", "binned", "superkmer"], default="auto",
+    ap.add_argument("--path", choices=["auto", "direct", "binned"], default="auto",
                     help="count pipeline (auto: the engine's choice; the others force it, for profiles and A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=10_000_000)
@@ -187,7 +187,7 @@ def run_count(args, world, rank, local_rank):
     local_hint = per_batch if len(my_batches) <= 1 else int(per_batch * (0.4 + 0.62 * len(my_batches)))
     eng = KmerEngine(k, capacity_hint=local_hint, device=local_rank)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    eng.set_option("force_path", {"auto": 0, "direct": 1, "binned": 2, "superkmer": 3}[args.path])
+    eng.set_option("force_path", {"auto": 0, "direct": 1, "binned": 2}[args.path])
     merger = None
     if world > 1:
         from kmer_denovo_filter_amd.distributed import EngineOps, OwnerPartitionedCount
@@ -273,7 +273,7 @@ def run_count(args, world, rank, local_rank):
 
     steps = max(args.steps, 1)
     value = total_windows * args.steps / dt / 1e9
-    # The count is one pipeline of kernels per pass (binned / super-k-mer path) or one
+    # The count is one pipeline of kernels per pass (binned path) or one
     # kernel per chunk (direct path).  The roofline is taken over the whole pass:
     # algorithmic bytes of the pass / summed duration of its kernels, HIP events
     # on the launch stream (kdf_profile*).  rocprofv3's per-kernel averages of

@@ -77,29 +77,38 @@ int kdf_reserve(kdf_engine *h, uint64_t n_keys);
  * by the count calls since the last clear.  Any pointer may be NULL. */
 int kdf_stats(kdf_engine *h, uint64_t *capacity, uint64_t *distinct, uint64_t *windows);
 
+/* Count calls in insert mode are DEFERRED: a call partitions its batch (or, for small batches, only appends it to a
+ * pending stream) and returns; the table itself is updated when something reads it -- kdf_stats, kdf_query*,
+ * kdf_count_ge, kdf_export_*, kdf_scan_*, kdf_add_pairs*, kdf_reserve, kdf_set_option -- or when the pending work
+ * fills its budget, so that a sample streamed in hundreds of batches pays the table rewrite of the binned pipeline
+ * once per flush, not once per batch (`jellyfish count` over the whole `samtools fasta` pipe,
+ * discovery/pipeline.py:106-172).  kdf_flush applies everything pending now; errors of deferred work (a table that
+ * cannot grow ...) surface there or in the call that triggered the flush.  kdf_clear drops pending work. */
+int kdf_flush(kdf_engine *h);
+
 /* Tuning knobs and counters (tests force either kernel path through these):
- *   options  "force_path" 0 auto / 1 direct global-table kernels / 2 binned
- *            LDS-bucket pipeline / 3 super-k-mer pipeline (minimizer-bucketed table, 16 <= k <= 32;
- *            chosen on an EMPTY table, which then keeps that layout until kdf_clear); "sk_min_k" (auto:
- *            smallest k that takes the super-k-mer pipeline); "binned_min_positions" (stream positions from
- *            which count calls take the binned path); "key_parts" / "key_part" (count only
+ *   options  "force_path" 0 auto / 1 direct global-table kernels / 2 binned LDS-bucket pipeline (every count call
+ *            partitions its batch at once) / 4 count --if through the sieve only; "binned_min_positions" (pending
+ *            positions below which a flush uses the direct kernels); "key_parts" / "key_part" (count only
  *            the windows whose key lies in slice key_part of key_parts of the key space --
  *            ranges of the LOW 16 hash bits, so a slice spreads over the whole table -- so that
  *            a sample whose distinct k-mers exceed one table is counted slice by slice over
  *            the same stream; insert mode only; 0/1 = everything); "binned_max_positions" (positions per
- *            binned pass, <= 2^31: longer streams take several passes); "binned_filtered_min_log2cap"
- *            "sk_auto" (1: big batches of narrow keys from k = sk_min_k on take the super-k-mer pipeline by
- *            themselves), "sk_balance", "binned_pool", "binned_cells", "sieve_bits" (bits per filter key; 0 = by size);
- *            force_path 4 = count --if through the sieve only; "binned_bytes_per_position" (a count call goes
- *            binned only when positions x this >= table bytes: a binned pass rewrites the whole table; default 70);
+ *            partition pass, <= 2^31: longer streams take several passes); "binned_filtered_min_log2cap";
+ *            "sieve_bits" (bits per filter key; 0 = by size); "binned_bytes_per_position" (a flush goes
+ *            binned only when pending positions x this >= table bytes: kernel C rewrites the whole table; default 70);
+ *            "defer" (1 default; 0: every count call ends with a flush), "defer_max_bytes" (budget of the ring of
+ *            partitioned entries, 0 = 40 % of the device's memory), "l1_positions" (size from which the pending
+ *            stream of small batches is partitioned, default 2^30), "l1_direct_positions" (batches from this size on
+ *            are partitioned where they lie, default 2^28);
  *            "hash_shift" (0..8, empty table only: the home slot ignores that many top hash bits -- the table of
  *            an OWNER rank of the multi-GPU merge, see kdf_add_pairs_multi_dev; such an engine counts through the
  *            direct kernels only); "merge_min_pairs" (below this many pairs kdf_add_pairs* skips the bucket merge)
- *   stats    "binned_passes", "replayed_buckets", "heavy_buckets" (buckets of skewed passes that were shared by
- *            several workgroups), "log2cap", "bucket_bits", "layout" (0 hash, 1 minimizer-bucketed,
- *            2 with the balanced assignment table), "binned_pool", "binned_cells", "hash_shift",
- *            "last_count_path" (0 direct / 1 binned / 2 super-k-mer / 3 sieve), "last_merge_path" (1 LDS bucket
- *            merge, 2 global atomics), "sk_passes", "sk_spills", "sk_failed_buckets", "sk_fallbacks", "ovf_log2cap" */
+ *   stats    "binned_passes" (partition passes), "flushes" (kernel C launches), "pending_passes",
+ *            "pending_positions", "ring_bytes", "replayed_buckets", "heavy_buckets" (buckets of skewed flushes that
+ *            were shared by several workgroups), "log2cap", "bucket_bits", "hash_shift", "defer",
+ *            "last_count_path" (0 direct / 1 binned / 3 sieve), "last_merge_path" (1 LDS bucket
+ *            merge, 2 global atomics) */
 int kdf_set_option(kdf_engine *h, const char *name, int64_t value);
 /* Free / total HBM of a device (hipMemGetInfo): the child-count mirror sizes "key_parts" with it. */
 int kdf_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);

@@ -27,6 +27,7 @@ SYMBOLS = [
     ("kdf_clear", c_int, [_P]),
     ("kdf_reserve", c_int, [_P, c_uint64]),
     ("kdf_stats", c_int, [_P, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
+    ("kdf_flush", c_int, [_P]),
     ("kdf_set_option", c_int, [_P, c_char_p, c_int64]),
     ("kdf_get_stat", c_int, [_P, c_char_p, POINTER(c_int64)]),
     ("kdf_profile", c_int, [_P, c_int]),

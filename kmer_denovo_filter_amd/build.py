@@ -23,7 +23,7 @@ _SOURCES = [
     ("kdf_host.cpp", ["-O2", "-x", "c++"]),          # host only: no device pass
 ]
 # every header any source includes: a header-only edit must trigger a rebuild
-_DEPS = ["kdf_device.h", "kdf_binned.h", "kdf_sk.h", "kdf_merge.h", os.path.join(_INC, "kdf.h")]
+_DEPS = ["kdf_device.h", "kdf_binned.h", "kdf_merge.h", os.path.join(_INC, "kdf.h")]
 
 
 def _newer(target: str, deps) -> bool:

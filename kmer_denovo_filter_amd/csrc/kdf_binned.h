@@ -3,21 +3,28 @@
 // The table (kdf_device.h) is an array of buckets of 2^bucket_bits slots; a
 // key's bucket is the top bits of its hash.  Random probes into an HBM table
 // move a 64-128 B sector per 8 useful bytes and pay a device atomic per window.
-// Instead, a batch of reads is processed as
+// Instead, a batch of reads is PARTITIONED
 //
 //   A0  histogram of the coarse bin (top c1 hash bits) of every valid window
-//   A1  extract canonical k-mers again and scatter them to their coarse bin:
+//   A1  extract canonical k-mers again and scatter their STORED FORM h (kdf_device.h: the hash is a bijection,
+//       so the entry IS the hash and no later stage evaluates it again) to their coarse bin:
 //       LDS counting sort per slab -> coalesced run writes
 //   B   every CHUNK-entry chunk of a coarse bin is sorted IN PLACE by the next
 //       c2 hash bits; a per-chunk offset table locates each fine run
 //       (no global fine histogram, immune to multiplicity skew)
+//
+// into the engine's entry RING, pass after pass (a streamed sample is many batches into one table), and the ring is
+// APPLIED to the table only when something needs the table (dump / query / stats ...) or the ring is full:
+//
 //   C   one workgroup per table bucket: bucket slice (keys+counts) lives in
-//       LDS, the bucket's runs are gathered from all chunks of its coarse bin
+//       LDS, the bucket's runs are gathered from all chunks of its coarse bin IN EVERY PENDING PASS
 //       and inserted / probed with LDS atomics, the slice is written back once.
 //       Transactional per bucket: a bucket that overflows is left untouched in
 //       HBM and flagged; the host grows the table and replays those buckets
-//       through the global-atomic path (D).
+//       through the global-atomic path (kb_replay_kernel).
 //
+// Kernel C reads and rewrites every bucket of the table whatever the batches hold (0.5 ms per GB of table): deferring
+// it over the pending passes is what makes a streamed sample run at the single-batch rate.
 // All of it is placement independent: no workgroup reads another workgroup's
 // output inside a launch.
 #pragma once
@@ -28,22 +35,21 @@
 #define KB_F_BITS_MAX 9                  // used only when the table has more buckets than 2^(C1_MAX+8)
 #define KB_F         (1 << KB_F_BITS_MAX)  // LDS array size for the fine histogram
 #define KB_C1_MAX    10                  // coarse bins <= 1024
+#define KB_MAX_PASS  64                  // pending passes one kernel C can apply
 // Bucket kernel: 768 threads = 12 waves per workgroup, two workgroups per CU (LDS) = 6 waves per SIMD,
-// which needs <= 80 VGPRs (amdgpu_waves_per_eu below; 78 used with 12 entries in flight per lane).  Measured on
+// which needs <= 80 VGPRs (amdgpu_waves_per_eu below).  Measured on
 // the bench pass: 512 threads x 20 entries (4 waves per SIMD) 6.16 ms, 768 x 12 5.4 ms, 1024 x 8 (8 per SIMD,
 // spills) 6.0 ms; thread counts whose waves do not divide evenly over the four SIMDs (640, 896) leave one
 // workgroup per CU (9-10 ms).  12 x 768 = 9216 entries per batch also covers the bench's ~8.9 K entries per
-// bucket in one batch with 11.6 of the 12 waves busy.  Past six waves nothing more comes: with two keys resolved
-// together instead of four the kernel fits 64 VGPRs without spilling, and 1024 threads x 10 or 12 entries at 8 waves
-// per SIMD then take 5.7-5.8 ms; lookahead 1 / 3 instead of 2: 5.9 / 5.4-5.5 ms.
+// bucket in one batch with 11.6 of the 12 waves busy.
 #ifndef KB_C_THREADS
 #define KB_C_THREADS 768
 #endif
 #ifndef KB_C_EPB_N
-#define KB_C_EPB_N 12                    // VAR 1, narrow keys: entries per thread and batch (a multiple of 4)
+#define KB_C_EPB_N 12                    // narrow keys: entries per thread and batch (a multiple of 4)
 #endif
 #ifndef KB_C_EPB_W
-#define KB_C_EPB_W 8                     // VAR 1, wide keys (4 measured the same, 12 spills)
+#define KB_C_EPB_W 8                     // wide keys (4 measured the same, 12 spills)
 #endif
 #ifndef KB_C_THREADS_W
 #define KB_C_THREADS_W 512                // wide keys: 2048-slot buckets hold ~3 K entries; 512 x 8 covers them and three workgroups fit a CU
@@ -64,58 +70,54 @@ template <> struct KbCfg<1> { static constexpr int WPT = 16, CHUNK = 16384; };  
 // (WPT = 8 for narrow keys -- 8 K slabs, two workgroups per CU at 8 waves per SIMD -- was measured at 8.6 ms for A1
 // against 4.6: the runs halve and 64 VGPRs spill.)
 template <> struct KbCfg<2> { static constexpr int WPT = 8,  CHUNK = 8192;  };   // 16-byte entries
-// Wide entries travel as 16-byte (lo, hi) structs: one dwordx4 / ds_*_b128 per entry instead
+// Wide entries travel as 16-byte (h, hi) structs: one dwordx4 / ds_*_b128 per entry instead
 // of two 8-byte accesses to two arrays (runs are short: 9 entries in A1, 16 in C).
 struct __attribute__((aligned(16))) KbEnt2 { uint64_t lo, hi; };
 
 struct KbPlan {
     uint32_t c1;            // coarse bits
-    uint32_t c2;            // fine bits (<= KB_F_BITS)
-    uint32_t sub_bits;      // table buckets per partition bucket = 2^sub_bits
+    uint32_t c2;            // fine bits (<= KB_F_BITS_MAX)
+    uint32_t sub_bits;      // table buckets per partition bucket = 2^sub_bits (a table that grew since the partition: more)
     uint32_t log2cap, bucket_bits;
     uint32_t off_stride;    // entries per row of chunk_off = 2^c2 + 1
     uint32_t key_parts, key_part;   // KdfTable::key_parts: windows of other key-space slices are dropped in A0 / A1
-    uint32_t dbg;           // experiments only (bucket kernel, plain-loop variant): 1 skip LDS insert, 4 skip write-back
-    uint32_t cells;         // 1: the partition was built without a histogram pass (fixed cells); the windows A1 counted wait in totals[5]
-    uint32_t cell_stride;   // cells: entries from one cell's base to the next (CHUNK + a pad: cells that are exactly 128 KB apart
-                            // advance in lockstep through the same HBM channels)
+    uint32_t dbg;           // experiments only
+    uint32_t n_pass;        // pending passes kernel C applies (1 .. KB_MAX_PASS)
 };
 
-// device scratch shared by the kernels of one pass
+// One partitioned pass in the ring (device resident, written by kb_scan1_kernel).
+struct KbPass {
+    unsigned long long ent_base;                          // first entry of the pass in the ring (entries)
+    unsigned long long chunk_base;                        // first row of the pass in chunk_off
+    unsigned long long n_entries, n_chunks;
+    unsigned long long bin_start[(1 << KB_C1_MAX) + 1];   // first entry of each coarse bin, relative to ent_base
+    unsigned long long chunk_first[(1 << KB_C1_MAX) + 1]; // first chunk of each coarse bin, relative to chunk_base
+};
+
+// device scratch shared by the kernels of the binned path
 struct KbScratch {
-    unsigned long long *hist1;      // [2^c1]
-    unsigned long long *bin_start;  // [2^c1 + 1]
+    unsigned long long *hist1;      // [2^c1] (per pass, between A0 and A1)
     uint32_t *hist_wg;              // [n_wg][2^c1] per-workgroup coarse histogram
     uint32_t *wg_base;              // [n_wg][2^c1] exclusive prefix of hist_wg over the workgroups
-    unsigned long long *chunk_first;// [2^c1 + 1]
-    unsigned long long *totals;     // [4]: n_entries, n_chunks, n_failed, claimed
-    unsigned int *failed_flag;      // [1]: set when the scatter pass disagrees with the histogram pass
-    uint32_t *chunk_off;            // [n_chunks][2^c2 + 1]
-    uint32_t *failed;               // bitmap over TABLE buckets (2^(c1+c2+sub_bits) bits)
-    uint64_t *ent_lo;               // entries (keys); wide keys: an array of (lo, hi) pairs, 16 B each (kb_ent2)
-    // pool variant of the scatter (kb_scatter2_kernel): no histogram pass, the runs go to 4 KB chunks taken from a pool
-    uint64_t *pool;                 // [max_chunks][KB_PCH entries]
-    uint32_t *chunk_bin, *chunk_pos, *chunk_fill, *chunk_list;   // [max_chunks]
-    uint32_t *bin_nchunks;          // [2^c1]
-    uint32_t *bin_chunk_start;      // [2^c1 + 1]
-    uint32_t *pool_ctr;             // [0] chunks taken
-    uint32_t max_chunks, pad2;
-    // heavy buckets of a skewed pass (kb_heavy_slice_kernel): [0] how many, their ids, staged (key, count) pairs
+    unsigned long long *totals;     // [16]: 0 entries (all pending passes), 2 failed buckets, 4 heavy buckets, 7 skew flag
+    unsigned int *failed_flag;      // [1]: set when a scatter pass disagrees with its histogram pass
+    uint32_t *chunk_off;            // [chunks in the ring][2^c2 + 1]
+    uint32_t *failed;               // bitmap over TABLE buckets
+    uint64_t *ent;                  // the entry ring: stored forms h; wide keys: (h, hi) pairs, 16 B each
+    KbPass *pass;                   // [KB_MAX_PASS]
+    // heavy buckets of a skewed flush (kb_heavy_slice_kernel): [0] how many, their ids, staged (key, count) pairs
     uint32_t *hv_ctr;               // [4]
     uint32_t *hv_bucket, *hv_n, *hv_failed;   // [KB_HV_MAX]
     uint64_t *hv_key;               // [KB_HV_MAX][KB_HV_SLICES << 12]
     uint32_t *hv_cnt;
 };
 #ifndef KB_HV_MAX
-#define KB_HV_MAX    64u                             // heavy buckets split per pass (further ones are processed the ordinary way)
+#define KB_HV_MAX    64u                             // heavy buckets split per flush (further ones are processed the ordinary way)
 #endif
 #define KB_HV_SLICES 32u                             // workgroups that share one heavy bucket's runs
 #ifndef KB_C_HEAVY
 #define KB_C_HEAVY   65536u                          // entries (first 256 runs) from which a bucket counts as heavy: ~7x a bucket's share at bench load
 #endif
-#define KB_GROUP 32                                  // pool chunks per fine-sort group
-#define KB_PCH(KW) (KbCfg<KW>::CHUNK / KB_GROUP)     // entries per pool chunk: 4 KB for either key width
-#define KB_NOCHUNK 0xFFFFFFFFu
 
 __device__ __forceinline__ uint32_t kb_coarse(const KbPlan &p, uint64_t h) {
     return p.c1 ? (uint32_t)(h >> (64 - p.c1)) : 0u;
@@ -126,7 +128,7 @@ __device__ __forceinline__ uint32_t kb_fine(const KbPlan &p, uint64_t h) {
 
 // block-wide exclusive scan of n <= KB_THREADS uint32 values held one per
 // thread (threads >= n pass 0); returns the exclusive prefix, total via *tot.
-__device__ __forceinline__ uint32_t kb_block_exscan(uint32_t v, uint32_t *wsum /* >= 16 words LDS */, uint32_t *tot) {
+__device__ __forceinline__ uint32_t kb_block_exscan(uint32_t v, uint32_t *wsum /* >= 17 words LDS */, uint32_t *tot) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     uint32_t inc = v;
 #pragma unroll
@@ -199,8 +201,7 @@ struct KbWindows {
             g0 = base >= 64 ? (fhi >> (base - 64)) : kdf_funnel(flo, fhi, base);
             g1 = base >= 64 ? 0ull : (fhi >> base);
         } else {
-            // Wide keys, the same idea over the 192-bit span (round 1 reversed two words and shifted by runtime amounts
-            // PER WINDOW: 127 vector instructions per window in A0 against 39 for narrow keys).  R = the span with its 96
+            // Wide keys, the same idea over the 192-bit span.  R = the span with its 96
             // two-bit groups reversed = (rev2(e0) : rev2(e1) : rev2(e2)); base j sits at bits 2 (95 - j) of R, so the
             // forward k-mer of window u is (R >> 2 (96 - k - u)) & mask(2k).  R is shifted ONCE by the runtime part
             // 2 (96 - k - (WPT - 1)); key(u) then shifts by the compile-time 2 (WPT - 1 - u).
@@ -229,6 +230,11 @@ struct KbWindows {
             lo = fw ? flo : rlo; hi = fw ? fhi : rhi;
         }
     }
+    // stored form of window u: h (and the key's high word as it is)
+    __device__ __forceinline__ void stored(int u, uint64_t &h, uint64_t &hi) const {
+        uint64_t lo; key(u, lo, hi);
+        h = kdf_hash(lo, hi);
+    }
 };
 
 // A0: persistent workgroups.  Workgroup w owns slabs [w*spw, (w+1)*spw) in BOTH
@@ -253,8 +259,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_hist1_kernel(
         win.load(packed, invalid, tile, n_tiles, threadIdx.x % TPT, k);
 #pragma unroll
         for (int u = 0; u < WPT; ++u) {
-            uint64_t lo, hi; win.key(u, lo, hi);
-            const uint64_t hsh = kdf_hash(lo, hi);
+            uint64_t hsh, hi; win.stored(u, hsh, hi);
             const bool ok = ((win.valid >> u) & 1) && (!SLICED || kdf_slice(hsh, plan.key_parts) == plan.key_part);
             const uint32_t bin = ok ? kb_coarse(plan, hsh) : (uint32_t)(1 << KB_C1_MAX);   // dummy counter
             atomicAdd(&hist[bin], 1u);
@@ -282,10 +287,13 @@ __global__ __launch_bounds__(256) void kb_colscan_kernel(KbPlan plan, KbScratch 
     if (threadIdx.x == 0) s.hist1[b] = carry;
 }
 
-// single workgroup: bin starts, chunk layout
-__global__ __launch_bounds__(KB_THREADS) void kb_scan1_kernel(KbPlan plan, KbScratch s, uint32_t chunk, KdfCtl *ctl) {
+// single workgroup: bin starts and chunk layout of pass `pass_idx`, whose entries start at ent_base of the ring and
+// whose chunk_off rows start at chunk_base (both chosen by the host from upper bounds: no host round trip)
+__global__ __launch_bounds__(KB_THREADS) void kb_scan1_kernel(KbPlan plan, KbScratch s, uint32_t pass_idx, unsigned long long ent_base,
+                                                              unsigned long long chunk_base, uint32_t chunk, KdfCtl *ctl) {
     __shared__ unsigned long long a[(1 << KB_C1_MAX) + 1], c[(1 << KB_C1_MAX) + 1];
     const int nb = 1 << plan.c1;
+    KbPass *P = s.pass + pass_idx;
     if (threadIdx.x == 0) {
         unsigned long long acc = 0, cacc = 0;
         for (int i = 0; i < nb; ++i) {
@@ -297,17 +305,13 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scan1_kernel(KbPlan plan, KbScr
         unsigned long long mx = 0;
         for (int i = 0; i < nb; ++i) mx = s.hist1[i] > mx ? s.hist1[i] : mx;
         // skewed: one coarse bin holds more than twice its share (a uniform hash keeps the bins within a few per cent)
-        s.totals[7] = (nb > 1 && mx * (unsigned long long)nb > 2 * acc + 65536ull * nb) ? 1ull : 0ull;
-        s.totals[0] = acc; s.totals[1] = cacc; s.totals[2] = 0; s.totals[3] = 0; s.totals[4] = 0; s.failed_flag[0] = 0;
-        for (int i = 9; i < 16; ++i) s.totals[i] = 0;          // diagnostic stamps
+        if (nb > 1 && mx * (unsigned long long)nb > 2 * acc + 65536ull * nb) s.totals[7] = 1ull;
+        s.totals[0] += acc;
+        P->ent_base = ent_base; P->chunk_base = chunk_base; P->n_entries = acc; P->n_chunks = cacc;
         if (acc) atomicAdd(&ctl->windows[0], acc);
     }
-    if (s.hv_ctr) {
-        if (threadIdx.x == 0) s.hv_ctr[0] = 0;
-        if (threadIdx.x < KB_HV_MAX) { s.hv_n[threadIdx.x] = 0; s.hv_failed[threadIdx.x] = 0; }
-    }
     __syncthreads();
-    for (int i = threadIdx.x; i <= nb; i += KB_THREADS) { s.bin_start[i] = a[i]; s.chunk_first[i] = c[i]; }
+    for (int i = threadIdx.x; i <= nb; i += KB_THREADS) { P->bin_start[i] = a[i]; P->chunk_first[i] = c[i]; }
 }
 
 // A1: same slab ownership as A0.  Each workgroup keeps a private cursor per bin
@@ -325,53 +329,33 @@ __device__ __forceinline__ void kb_lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-// CELLS: no histogram pass ran.  Every (bin, workgroup) pair owns a CELL of CHUNK entries -- chunk number
-// bin * gridDim.x + workgroup of the entry buffer -- and the workgroup's cursor of the bin starts at the cell's base; the
-// cell's fill goes to hist_wg[chunk] at the end and the valid windows are counted here.  A cell that would overflow
-// (a bin far above the mean inside one workgroup's slabs) raises failed_flag: the later stages then do nothing and the
-// host redoes the pass with the exact layout (A0 first).
-template <int KW, bool SLICED, bool CELLS = false>
+template <int KW, bool SLICED>
 __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
     const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid, uint64_t n_tiles, int k,
-    KbPlan plan, KbScratch s, uint32_t slabs_per_wg, KdfCtl *ctl = nullptr)
+    KbPlan plan, KbScratch s, uint32_t pass_idx, uint32_t slabs_per_wg)
 {
     constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT, SLAB = KB_THREADS * WPT;
     constexpr uint32_t TILES_PER_SLAB = KB_THREADS / TPT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t *slo = (uint64_t *)smem;                                   // [SLAB + 1]: last = trash slot
-    KbEnt2 *s2 = (KbEnt2 *)smem;                                        // [SLAB + 1] wide: the image holds (lo, hi) pairs
-    KbEnt2 *const ent2 = (KbEnt2 *)s.ent_lo;
+    KbEnt2 *s2 = (KbEnt2 *)smem;                                        // [SLAB + 1] wide: the image holds (h, hi) pairs
+    KbEnt2 *const ent2 = (KbEnt2 *)s.ent;
     unsigned long long *gcur = (unsigned long long *)(smem + (size_t)(SLAB + 2) * 8 * KW);   // next free entry of this WG per bin
-    unsigned long long *gend = gcur + (1 << KB_C1_MAX);                 // [512] end of this WG's range (guard)
+    unsigned long long *gend = gcur + (1 << KB_C1_MAX);                 // end of this WG's range (guard)
     uint32_t *hist = (uint32_t *)(gend + (1 << KB_C1_MAX));             // [bins + 1]: last = dummy counter of invalid windows
     uint32_t *offs = hist + (1 << KB_C1_MAX) + 32;                      // [bins + 1]: offs[DUMMY] = trash slot
-    uint32_t *wsum = offs + (1 << KB_C1_MAX) + 32;                      // [32]
     constexpr int DUMMY = 1 << KB_C1_MAX;
     const int nb = 1 << plan.c1;
+    const KbPass *P = s.pass + pass_idx;
     if (threadIdx.x == 0) { hist[DUMMY] = 0; offs[DUMMY] = (uint32_t)SLAB; }
-    if (CELLS && threadIdx.x == 0) wsum[31] = 0, wsum[30] = 0;          // valid windows of this workgroup (64-bit, lane 63 adds)
     for (int i = threadIdx.x; i < nb; i += KB_THREADS) {
         hist[i] = 0;
-        if constexpr (CELLS) {
-            const unsigned long long st = ((unsigned long long)i * gridDim.x + blockIdx.x) * plan.cell_stride;
-            gcur[i] = st; gend[i] = st + KbCfg<KW>::CHUNK;
-        } else {
-            const unsigned long long st = s.bin_start[i] + s.wg_base[(uint64_t)blockIdx.x * nb + i];
-            gcur[i] = st;
-            gend[i] = st + s.hist_wg[(uint64_t)blockIdx.x * nb + i];
-        }
+        const unsigned long long st = P->ent_base + P->bin_start[i] + s.wg_base[(uint64_t)blockIdx.x * nb + i];
+        gcur[i] = st;
+        gend[i] = st + s.hist_wg[(uint64_t)blockIdx.x * nb + i];
     }
     __syncthreads();
-    // CELLS: the workgroups are persistent (one per CU) and CLAIM batches of slabs_per_wg slabs from a counter, so a CU
-    // that runs slower takes fewer batches (a static split ran as long as the slowest CU: +20 % on the narrow scatter)
-    uint64_t slab0 = (uint64_t)blockIdx.x * slabs_per_wg;
-    auto claim = [&]() {
-        if (threadIdx.x == 0) wsum[28] = (uint32_t)atomicAdd(&s.totals[6], 1ull);
-        __syncthreads();
-        slab0 = (uint64_t)wsum[28] * slabs_per_wg;
-        __syncthreads();
-    };
-    if constexpr (CELLS) claim();
+    const uint64_t slab0 = (uint64_t)blockIdx.x * slabs_per_wg;
     constexpr int GL = 2 * WPT;                                         // lanes that copy one bin's run = its mean length (wide keys: 16 lanes instead of 32 took A1 from 8.9 to 7.9 ms)
     const int half = threadIdx.x / GL, lane32 = threadIdx.x % GL;
     constexpr int NHALF = KB_THREADS / GL;
@@ -380,8 +364,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
     // copy-out + cursor update.  The next slab's input words are fetched before
     // the current slab is processed, so waves do not reach the first barrier
     // skewed by global-load latency.
-    for (;;) {
-    if (slab0 * TILES_PER_SLAB >= n_tiles) break;                      // uniform
+    if (slab0 * TILES_PER_SLAB >= n_tiles) return;                     // uniform
     KbWindows<KW> win;
     win.load(packed, invalid, slab0 * TILES_PER_SLAB + threadIdx.x / TPT, n_tiles, threadIdx.x % TPT, k);
     for (uint32_t sl = 0; sl < slabs_per_wg; ++sl) {
@@ -400,9 +383,8 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
         uint32_t br[WPT];                       // bin << 16 | rank  (rank < SLAB <= 16384)
 #pragma unroll
         for (int u = 0; u < WPT; ++u) {
-            uint64_t lo, hi; win.key(u, lo, hi);
-            klo[u] = lo; if constexpr (KW == 2) khi[u] = hi;
-            const uint64_t hsh = kdf_hash(lo, hi);
+            uint64_t hsh, hi; win.stored(u, hsh, hi);
+            klo[u] = hsh; if constexpr (KW == 2) khi[u] = hi;
             const bool ok = ((win.valid >> u) & 1) && (!SLICED || kdf_slice(hsh, plan.key_parts) == plan.key_part);
             const uint32_t bin = ok ? kb_coarse(plan, hsh) : (uint32_t)DUMMY;
             br[u] = bin << 16;
@@ -421,7 +403,6 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
             for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if ((int)threadIdx.x >= o) inc += t; }
             uint32_t run = inc - sum;
             for (int i = 0; i < per; ++i) if (b0 + i < nb) { offs[b0 + i] = run; run += hist[b0 + i]; }
-            if (CELLS && threadIdx.x == 63) atomicAdd((unsigned long long *)&wsum[30], (unsigned long long)inc);   // lane 63: the slab's valid windows
         }
         kb_lds_barrier();                                               // B2: offsets ready
         {
@@ -452,7 +433,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
             } else {
                 for (uint32_t i = lane32; i < n; i += GL) {
                     if constexpr (KW == 2) ent2[g + i] = s2[o + i];
-                    else s.ent_lo[g + i] = slo[o + i];
+                    else s.ent[g + i] = slo[o + i];
                 }
             }
             if (lane32 == 0) { gcur[bin] = g + n; hist[bin] = 0; }      // this half-wave owns the bin
@@ -461,60 +442,33 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
         kb_lds_barrier();                                               // B4: hist is zero, image free (stores still draining)
         win = nxt;
     }
-    if constexpr (!CELLS) break;
-    claim();
-    }
-    if constexpr (CELLS) {
-        for (int i = threadIdx.x; i < nb; i += KB_THREADS) {
-            const unsigned long long chunk = (unsigned long long)i * gridDim.x + blockIdx.x;
-            s.hist_wg[chunk] = (uint32_t)(gcur[i] - chunk * plan.cell_stride);
-        }
-        if (threadIdx.x == 0) {
-            // not into ctl->windows yet: if a cell overflowed somewhere the pass is redone (kernel C adds totals[5])
-            const unsigned long long w = *(unsigned long long *)&wsum[30];
-            if (w) atomicAdd(&s.totals[5], w);
-        }
-    }
 }
 
-// cells: the arrays kernel C reads, for nbins x n_wg cells of CHUNK entries (chunk j of the bins starts at j * CHUNK)
-__global__ __launch_bounds__(KB_THREADS) void kb_cellscan_kernel(KbPlan plan, KbScratch s, uint32_t chunk_entries, uint32_t n_wg) {
-    const int nb = 1 << plan.c1;
-    for (int i = threadIdx.x; i <= nb; i += KB_THREADS) { s.chunk_first[i] = (unsigned long long)i * n_wg; s.bin_start[i] = (unsigned long long)i * n_wg * chunk_entries; }
-    if (threadIdx.x == 0) {
-        s.totals[0] = 0; s.totals[1] = (unsigned long long)nb * n_wg; s.totals[2] = 0; s.totals[3] = 0; s.totals[4] = 0; s.totals[5] = 0; s.totals[6] = 0; s.totals[7] = 0;
-        for (int i = 9; i < 16; ++i) s.totals[i] = 0;             // (totals[8] holds failed_flag: the host cleared it)
-    }
-}
-
-// B: one workgroup per chunk; in-place sort by fine bin + offset table
-template <int KW, bool CELLS = false>
-__global__ __launch_bounds__(KB_THREADS) void kb_finesort_kernel(KbPlan plan, KbScratch s)
+// B: one workgroup per chunk of pass `pass_idx`; in-place sort by fine bin + offset table
+template <int KW>
+__global__ __launch_bounds__(KB_THREADS) void kb_finesort_kernel(KbPlan plan, KbScratch s, uint32_t pass_idx)
 {
     constexpr int CHUNK = KbCfg<KW>::CHUNK, EPT = CHUNK / KB_THREADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t *slo = (uint64_t *)smem;
     KbEnt2 *s2 = (KbEnt2 *)smem;
-    KbEnt2 *const ent2 = (KbEnt2 *)s.ent_lo;
+    KbEnt2 *const ent2 = (KbEnt2 *)s.ent;
     uint32_t *hist = (uint32_t *)(smem + (size_t)CHUNK * 8 * KW);       // [256]
     uint32_t *offs = hist + KB_F;                                        // [256]
     uint32_t *wsum = offs + KB_F;                                        // [32]
     unsigned long long &sh_start = *(unsigned long long *)(wsum + 32);
     uint32_t &sh_len = *(uint32_t *)(wsum + 34);
+    const KbPass *P = s.pass + pass_idx;
     const uint64_t chunk = blockIdx.x;
-    if (CELLS && s.failed_flag[0]) return;                  // a cell overflowed: the host redoes the pass, nothing may be used
-    if (chunk >= s.totals[1]) return;                       // the grid covers the largest possible number of chunks
-    if (CELLS) {
-        if (threadIdx.x == 0) { sh_start = chunk * (unsigned long long)plan.cell_stride; sh_len = s.hist_wg[chunk]; }
-    } else
+    if (chunk >= P->n_chunks) return;                       // the grid covers the largest possible number of chunks
     if (threadIdx.x == 0) {
         // locate the coarse bin of this chunk: chunk_first is ascending
         const int nb = 1 << plan.c1;
         int lo = 0, hi = nb;            // largest c with chunk_first[c] <= chunk
-        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (s.chunk_first[mid] <= chunk) lo = mid; else hi = mid; }
-        const unsigned long long st = s.bin_start[lo] + (chunk - s.chunk_first[lo]) * (unsigned long long)CHUNK;
-        const unsigned long long en = s.bin_start[lo + 1];
-        sh_start = st;
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (P->chunk_first[mid] <= chunk) lo = mid; else hi = mid; }
+        const unsigned long long st = P->bin_start[lo] + (chunk - P->chunk_first[lo]) * (unsigned long long)CHUNK;
+        const unsigned long long en = P->bin_start[lo + 1];
+        sh_start = P->ent_base + st;
         sh_len = (uint32_t)((en - st) < (unsigned long long)CHUNK ? (en - st) : (unsigned long long)CHUNK);
     }
     const int nf = 1 << plan.c2;
@@ -522,6 +476,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_finesort_kernel(KbPlan plan, Kb
     __syncthreads();
     const unsigned long long start = sh_start;
     const uint32_t len = sh_len;
+    const unsigned long long row = (P->chunk_base + chunk) * plan.off_stride;
     uint64_t klo[EPT], khi[KW == 2 ? EPT : 1];
     uint32_t br[EPT];
 #pragma unroll
@@ -529,14 +484,14 @@ __global__ __launch_bounds__(KB_THREADS) void kb_finesort_kernel(KbPlan plan, Kb
         const uint32_t i = e * KB_THREADS + threadIdx.x;
         if (i < len) {
             if constexpr (KW == 2) { const KbEnt2 v = ent2[start + i]; klo[e] = v.lo; khi[e] = v.hi; }
-            else klo[e] = s.ent_lo[start + i];
+            else klo[e] = s.ent[start + i];
         }
     }
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const uint32_t i = e * KB_THREADS + threadIdx.x;
         if (i < len) {
-            const uint32_t f = kb_fine(plan, kdf_hash(klo[e], KW == 2 ? khi[e] : 0));
+            const uint32_t f = kb_fine(plan, klo[e]);                   // the entry is the hash
             br[e] = (f << 16) | atomicAdd(&hist[f], 1u);
         }
     }
@@ -546,9 +501,9 @@ __global__ __launch_bounds__(KB_THREADS) void kb_finesort_kernel(KbPlan plan, Kb
         const uint32_t ex = kb_block_exscan(v, wsum, nullptr);
         if (threadIdx.x < nf) {
             offs[threadIdx.x] = ex;
-            s.chunk_off[chunk * plan.off_stride + threadIdx.x] = ex;
+            s.chunk_off[row + threadIdx.x] = ex;
         }
-        if (threadIdx.x == 0) s.chunk_off[chunk * plan.off_stride + nf] = len;
+        if (threadIdx.x == 0) s.chunk_off[row + nf] = len;
     }
     __syncthreads();
 #pragma unroll
@@ -563,274 +518,84 @@ __global__ __launch_bounds__(KB_THREADS) void kb_finesort_kernel(KbPlan plan, Kb
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < len; i += KB_THREADS) {
         if constexpr (KW == 2) {
-            // the sorted chunk goes back as chunk-local structure of arrays -- len lo words, then len hi
+            // the sorted chunk goes back as chunk-local structure of arrays -- len h words, then len hi
             // words, in the same 16 * len bytes -- because kernel C's gathers run faster on two 8-byte
             // streams than on 16-byte entries (measured: 15.5 vs 17.0 ms at k = 63)
             const KbEnt2 v = s2[i];
-            // (cells may be partly filled anywhere in a bin: kernel C then finds the hi words at + CHUNK, see kb_finesort2)
-            s.ent_lo[2 * start + i] = v.lo; s.ent_lo[2 * start + (CELLS ? (uint32_t)CHUNK : len) + i] = v.hi;
-        } else s.ent_lo[start + i] = slo[i];
-    }
-}
-
-
-// ---------------------------------------------------------------------------
-// A1 without A0.  The histogram pass existed only to give every (workgroup, bin) run an exact place in a contiguous
-// bin.  Here a workgroup writes its runs of a bin into 4 KB chunks it takes from a global pool (one thread per bin
-// takes the chunks a slab needs, all bins at once, next to the scan), so one pass over the stream is enough; the
-// fine sort then works on groups of KB_GROUP chunks of one bin (kb_poolscan / kb_chunklist / kb_finesort2 below) and
-// leaves the arrays kernel C reads -- chunk_first, bin_start, chunk_off, ent_lo -- with the meaning they always had
-// (a "chunk" of C is a group: bin_start[c] = chunk_first[c] * CHUNK, so chunk j of the bins starts at j * CHUNK).
-// (the kernel takes only the pointers it needs: the whole KbScratch costs ~40 SGPRs that spill into VGPR lanes,
-// and this kernel sits at the 128-VGPR limit of a 1024-thread workgroup)
-struct KbPool { uint64_t *pool; uint32_t *chunk_bin, *chunk_pos, *chunk_fill, *bin_nchunks, *pool_ctr; uint32_t max_chunks, c1, key_parts, key_part; };
-template <int KW, bool SLICED>
-__global__ __launch_bounds__(KB_THREADS) void kb_scatter2_kernel(
-    const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid, uint64_t n_tiles, int k,
-    KbPool s, uint32_t slabs_per_wg, KdfCtl *ctl)
-{
-    KbPlan plan{}; plan.c1 = s.c1; plan.key_parts = s.key_parts; plan.key_part = s.key_part;
-    constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT, SLAB = KB_THREADS * WPT, PCH = KB_PCH(KW);
-    constexpr uint32_t TILES_PER_SLAB = KB_THREADS / TPT;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t *slo = (uint64_t *)smem;                                   // [SLAB + 1]: last = trash slot
-    KbEnt2 *s2 = (KbEnt2 *)smem;
-    KbEnt2 *const pool2 = (KbEnt2 *)s.pool;
-    uint32_t *cur_chunk = (uint32_t *)(smem + (size_t)(SLAB + 2) * 8 * KW);   // [bins] this workgroup's open chunk of the bin
-    uint32_t *cur_fill = cur_chunk + (1 << KB_C1_MAX);                  // [bins]
-    uint32_t *nxt = cur_fill + (1 << KB_C1_MAX);                        // [bins] first of the chunks taken for the bin this slab
-    uint32_t *hist = nxt + (1 << KB_C1_MAX);                            // [bins + 1]: last = dummy counter of invalid windows
-    uint32_t *offs = hist + (1 << KB_C1_MAX) + 32;                      // [bins + 1]: offs[DUMMY] = trash slot
-    constexpr int DUMMY = 1 << KB_C1_MAX;
-    const int nb = 1 << plan.c1;
-    if (threadIdx.x == 0) { hist[DUMMY] = 0; offs[DUMMY] = (uint32_t)SLAB; }
-    for (int i = threadIdx.x; i < nb; i += KB_THREADS) { hist[i] = 0; cur_chunk[i] = KB_NOCHUNK; cur_fill[i] = 0; }
-    __syncthreads();
-    const uint64_t slab0 = (uint64_t)blockIdx.x * slabs_per_wg;
-    constexpr int GL = 2 * WPT;                                         // lanes that copy one bin's run = its mean length
-    const int grp = threadIdx.x / GL, lane_g = threadIdx.x % GL;
-    constexpr int NGRP = KB_THREADS / GL;
-    unsigned long long nwin = 0;
-    KbWindows<KW> win;
-    if (slab0 * TILES_PER_SLAB < n_tiles)
-        win.load(packed, invalid, slab0 * TILES_PER_SLAB + threadIdx.x / TPT, n_tiles, threadIdx.x % TPT, k);
-    for (uint32_t sl = 0; sl < slabs_per_wg; ++sl) {
-        if ((slab0 + sl) * TILES_PER_SLAB >= n_tiles) break;          // uniform
-        KbWindows<KW> nx;
-        {
-            const bool more = sl + 1 < slabs_per_wg;
-            nx.issue(packed, invalid, more ? (slab0 + sl + 1) * TILES_PER_SLAB + threadIdx.x / TPT : n_tiles,
-                     n_tiles, threadIdx.x % TPT, k);
-        }
-        uint64_t klo[WPT], khi[KW == 2 ? WPT : 1];
-        uint32_t br[WPT];                       // bin << 16 | rank
-#pragma unroll
-        for (int u = 0; u < WPT; ++u) {
-            uint64_t lo, hi; win.key(u, lo, hi);
-            klo[u] = lo; if constexpr (KW == 2) khi[u] = hi;
-            const uint64_t hsh = kdf_hash(lo, hi);
-            const bool ok = ((win.valid >> u) & 1) && (!SLICED || kdf_slice(hsh, plan.key_parts) == plan.key_part);
-            br[u] = (ok ? kb_coarse(plan, hsh) : (uint32_t)DUMMY) << 16;
-        }
-#pragma unroll
-        for (int u = 0; u < WPT; ++u) br[u] |= atomicAdd(&hist[br[u] >> 16], 1u) & 0xFFFFu;
-        kb_lds_barrier();                                               // B1: all ranks taken
-        if (threadIdx.x < 64) {
-            const int per = (nb + 63) >> 6;
-            const int b0 = threadIdx.x * per;
-            uint32_t sum = 0;
-            for (int i = 0; i < per; ++i) sum += (b0 + i < nb) ? hist[b0 + i] : 0;
-            uint32_t inc = sum;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if ((int)threadIdx.x >= o) inc += t; }
-            uint32_t run = inc - sum;
-            for (int i = 0; i < per; ++i) if (b0 + i < nb) { offs[b0 + i] = run; run += hist[b0 + i]; }
-            if (threadIdx.x == 63) nwin += inc;                         // the slab's valid windows (lane 63 holds the total)
-        }
-        kb_lds_barrier();                                               // B2: offsets ready
-        {
-            uint32_t pos[WPT];
-#pragma unroll
-            for (int u = 0; u < WPT; ++u) {
-                const uint32_t bin = br[u] >> 16;
-                pos[u] = offs[bin] + ((bin == (uint32_t)DUMMY) ? 0u : (br[u] & 0xFFFF));
-            }
-#pragma unroll
-            for (int u = 0; u < WPT; ++u) {
-                if constexpr (KW == 2) s2[pos[u]] = KbEnt2{klo[u], khi[u]};
-                else slo[pos[u]] = klo[u];
-            }
-        }
-        nx.finish();
-        asm volatile("" :: "v"(nx.e[0]), "v"(nx.e[1]), "v"(nx.valid));
-        // a thread per bin takes the chunks the bin's run needs beyond its open chunk: two independent atomics, all bins
-        // at once -- after the LDS scatter, when the slab's keys no longer occupy the registers (the kernel sits at the
-        // 128-VGPR limit of a 1024-thread workgroup).  The pool holds one entry per stream position plus every
-        // workgroup's open chunks: it cannot run out.
-        for (int bin = (int)threadIdx.x; bin < nb; bin += KB_THREADS) {
-            const uint32_t n = hist[bin], ch = cur_chunk[bin];
-            const uint32_t room = ch == KB_NOCHUNK ? 0u : (uint32_t)PCH - cur_fill[bin];
-            uint32_t id0 = KB_NOCHUNK;
-            if (n > room) {
-                const uint32_t need = (n - room + PCH - 1) / PCH;
-                id0 = atomicAdd(&s.pool_ctr[0], need);
-                const uint32_t pos0 = atomicAdd(&s.bin_nchunks[bin], need);
-                for (uint32_t q = 0; q < need; ++q) if (id0 + q < s.max_chunks) { s.chunk_bin[id0 + q] = (uint32_t)bin; s.chunk_pos[id0 + q] = pos0 + q; }
-            }
-            nxt[bin] = id0;
-        }
-        kb_lds_barrier();                                               // B3: sorted image complete, chunks taken
-        for (int bin = grp; bin < nb; bin += NGRP) {
-            const uint32_t n = hist[bin], o = offs[bin];
-            if (n == 0) continue;
-            uint32_t ch = cur_chunk[bin], fl = cur_fill[bin], nxc = nxt[bin], done = 0;
-            while (done < n) {
-                if (ch == KB_NOCHUNK || fl == (uint32_t)PCH) {
-                    if (lane_g == 0 && ch != KB_NOCHUNK && ch < s.max_chunks) s.chunk_fill[ch] = PCH;
-                    ch = nxc++; fl = 0;
-                }
-                const uint32_t take = min(n - done, (uint32_t)PCH - fl);
-                if (ch < s.max_chunks) {
-                    const size_t dst = (size_t)ch * PCH + fl;
-                    for (uint32_t i = lane_g; i < take; i += GL) {
-                        if constexpr (KW == 2) pool2[dst + i] = s2[o + done + i];
-                        else s.pool[dst + i] = slo[o + done + i];
-                    }
-                }
-                done += take; fl += take;
-            }
-            if (lane_g == 0) { cur_chunk[bin] = ch; cur_fill[bin] = fl; hist[bin] = 0; }
-        }
-        if (threadIdx.x == 0) hist[DUMMY] = 0;
-        kb_lds_barrier();                                               // B4: hist is zero, image free
-        win = nx;
-    }
-    for (int i = threadIdx.x; i < nb; i += KB_THREADS) {
-        const uint32_t ch = cur_chunk[i];
-        if (ch != KB_NOCHUNK && ch < s.max_chunks) s.chunk_fill[ch] = cur_fill[i];
-    }
-    if (threadIdx.x == 63 && nwin) atomicAdd(&ctl->windows[(blockIdx.x % KDF_SHARDS) * 16], nwin);
-}
-
-// bins -> chunk lists, groups of KB_GROUP chunks; leaves chunk_first / bin_start as kernel C reads them
-__global__ __launch_bounds__(KB_THREADS) void kb_poolscan_kernel(KbPlan plan, KbScratch s, uint32_t chunk_entries) {
-    __shared__ uint32_t a[(1 << KB_C1_MAX) + 1];
-    __shared__ unsigned long long g[(1 << KB_C1_MAX) + 1];
-    const int nb = 1 << plan.c1;
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0; unsigned long long gacc = 0;
-        for (int i = 0; i < nb; ++i) {
-            a[i] = acc; g[i] = gacc;
-            const uint32_t n = s.bin_nchunks[i];
-            acc += n; gacc += (n + KB_GROUP - 1) / KB_GROUP;
-        }
-        a[nb] = acc; g[nb] = gacc;
-        s.totals[7] = 0; s.totals[4] = 0; s.totals[0] = (unsigned long long)acc * (chunk_entries / KB_GROUP); s.totals[1] = gacc; s.totals[2] = 0; s.totals[3] = 0; s.failed_flag[0] = 0;
-        for (int i = 9; i < 16; ++i) s.totals[i] = 0;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i <= nb; i += KB_THREADS) { s.bin_chunk_start[i] = a[i]; s.chunk_first[i] = g[i]; s.bin_start[i] = g[i] * chunk_entries; }
-}
-__global__ __launch_bounds__(256) void kb_chunklist_kernel(KbScratch s) {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= min(s.pool_ctr[0], s.max_chunks)) return;
-    s.chunk_list[s.bin_chunk_start[s.chunk_bin[c]] + s.chunk_pos[c]] = c;
-}
-
-// B on groups of pool chunks: gather the group's entries, sort them by fine bin in LDS, write the sorted group to
-// ent_lo[group * CHUNK ...] (wide keys: lo words, then at + CHUNK the hi words) and its offset table
-template <int KW>
-__global__ __launch_bounds__(KB_THREADS) void kb_finesort2_kernel(KbPlan plan, KbScratch s)
-{
-    constexpr int CHUNK = KbCfg<KW>::CHUNK, EPT = CHUNK / KB_THREADS, PCH = KB_PCH(KW);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t *slo = (uint64_t *)smem;
-    KbEnt2 *s2 = (KbEnt2 *)smem;
-    const KbEnt2 *const pool2 = (const KbEnt2 *)s.pool;
-    uint32_t *hist = (uint32_t *)(smem + (size_t)CHUNK * 8 * KW);       // [KB_F]
-    uint32_t *offs = hist + KB_F;                                        // [KB_F]
-    uint32_t *wsum = offs + KB_F;                                        // [40]
-    uint32_t *cid = wsum + 40, *cfl = cid + KB_GROUP;                    // [KB_GROUP] chunk ids, fills
-    const uint64_t grp = blockIdx.x;
-    if (grp >= s.totals[1]) return;                                     // the grid covers the largest possible number of groups
-    const int nf = 1 << plan.c2;
-    for (int i = threadIdx.x; i < KB_F; i += KB_THREADS) hist[i] = 0;
-    if (threadIdx.x < KB_GROUP) {
-        const int nbn = 1 << plan.c1;
-        int lo = 0, hi = nbn;            // largest bin with chunk_first[bin] <= grp
-        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (s.chunk_first[mid] <= grp) lo = mid; else hi = mid; }
-        const uint32_t lc = s.bin_chunk_start[lo] + (uint32_t)(grp - s.chunk_first[lo]) * KB_GROUP + threadIdx.x;
-        const bool ok = lc < s.bin_chunk_start[lo + 1];
-        const uint32_t id = ok ? s.chunk_list[lc] : 0u;
-        cid[threadIdx.x] = id; cfl[threadIdx.x] = ok ? s.chunk_fill[id] : 0u;
-    }
-    __syncthreads();
-    uint64_t klo[EPT], khi[KW == 2 ? EPT : 1];
-    uint32_t br[EPT];
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const uint32_t i = e * KB_THREADS + threadIdx.x, c = i / PCH, o = i % PCH;
-        br[e] = KB_NOCHUNK;
-        if (o < cfl[c]) {
-            const size_t src = (size_t)cid[c] * PCH + o;
-            if constexpr (KW == 2) { const KbEnt2 v = pool2[src]; klo[e] = v.lo; khi[e] = v.hi; }
-            else klo[e] = s.pool[src];
-            br[e] = 0;
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        if (br[e] != KB_NOCHUNK) {
-            const uint32_t f = kb_fine(plan, kdf_hash(klo[e], KW == 2 ? khi[e] : 0));
-            br[e] = (f << 16) | atomicAdd(&hist[f], 1u);
-        }
-    }
-    __syncthreads();
-    {
-        const uint32_t v = threadIdx.x < nf ? hist[threadIdx.x] : 0;
-        uint32_t len = 0;
-        const uint32_t ex = kb_block_exscan(v, wsum, &len);
-        if (threadIdx.x < nf) { offs[threadIdx.x] = ex; s.chunk_off[grp * plan.off_stride + threadIdx.x] = ex; }
-        if (threadIdx.x == 0) { s.chunk_off[grp * plan.off_stride + nf] = len; wsum[39] = len; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        if (br[e] != KB_NOCHUNK) {
-            const uint32_t pos = offs[br[e] >> 16] + (br[e] & 0xFFFF);
-            if constexpr (KW == 2) s2[pos] = KbEnt2{klo[e], khi[e]};
-            else slo[pos] = klo[e];
-        }
-    }
-    __syncthreads();
-    const uint32_t len = wsum[39];
-    const uint64_t start = grp * (uint64_t)CHUNK;
-    for (uint32_t i = threadIdx.x; i < len; i += KB_THREADS) {
-        if constexpr (KW == 2) {
-            // chunk-local structure of arrays with a FIXED distance between a key's words (a group may be partly
-            // filled; kernel C takes min(entries left in the bin, CHUNK) as that distance, and bin_start makes it CHUNK)
-            const KbEnt2 v = s2[i];
-            s.ent_lo[2 * start + i] = v.lo; s.ent_lo[2 * start + CHUNK + i] = v.hi;
-        } else s.ent_lo[start + i] = slo[i];
+            s.ent[2 * start + i] = v.lo; s.ent[2 * start + len + i] = v.hi;
+        } else s.ent[start + i] = slo[i];
     }
 }
 
 // ---------------------------------------------------------------------------
 // C: one workgroup per TABLE bucket.
-enum { KB_MODE_INSERT = 0, KB_MODE_FILTERED = 1, KB_MODE_REPLAY = 2 };
+enum { KB_MODE_INSERT = 0, KB_MODE_FILTERED = 1 };
 
 __device__ __forceinline__ void kb_lds_sat_add(uint32_t *p, uint32_t add) {
     uint32_t old = atomicAdd(p, add);
     if (old + add < old || old + add == 0xFFFFFFFFu) atomicMax(p, 0xFFFFFFFFu);
 }
 
+// The runs of partition bucket (c, f) over every pending pass, as ONE flat list r = 0 .. n_runs - 1 (run = the bucket's
+// slice of one sorted chunk).  setup(): per pass the bin's first chunk row / first entry / end in LDS (one global latency
+// for all passes); locate(): run r -> (first entry, length, wide keys: distance from the h words to the hi words).
+#define KB_RI_LDS_BYTES ((KB_MAX_PASS + 2) * 4 + 3 * KB_MAX_PASS * 8)
+struct KbRunIndex {
+    uint32_t *ppref;                 // [KB_MAX_PASS + 1] runs of this bin before pass m
+    unsigned long long *prow, *pent, *pend;   // [KB_MAX_PASS] chunk_off row of the bin's first chunk / its first entry / the bin's end
+    __device__ __forceinline__ void bind(char *p) {
+        prow = (unsigned long long *)p; pent = prow + KB_MAX_PASS; pend = pent + KB_MAX_PASS; ppref = (uint32_t *)(pend + KB_MAX_PASS);
+    }
+    // all threads of the workgroup call it (it ends with a barrier); returns the number of runs
+    __device__ __forceinline__ uint32_t setup(const KbPlan &plan, const KbScratch &s, uint32_t c) {
+        if (threadIdx.x < 64) {
+            uint32_t n = 0;
+            if (threadIdx.x < plan.n_pass) {
+                const KbPass *P = s.pass + threadIdx.x;
+                const unsigned long long j0 = P->chunk_first[c], j1 = P->chunk_first[c + 1];
+                n = (uint32_t)(j1 - j0);
+                prow[threadIdx.x] = P->chunk_base + j0;
+                pent[threadIdx.x] = P->ent_base + P->bin_start[c];
+                pend[threadIdx.x] = P->ent_base + P->bin_start[c + 1];
+            }
+            uint32_t inc = n;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if ((int)threadIdx.x >= o) inc += t; }
+            if (threadIdx.x < KB_MAX_PASS) ppref[threadIdx.x + 1] = inc;
+            if (threadIdx.x == 0) ppref[0] = 0;
+        }
+        __syncthreads();
+        return ppref[plan.n_pass];
+    }
+    template <int KW>
+    __device__ __forceinline__ void locate(const KbPlan &plan, const KbScratch &s, uint32_t f, uint32_t r,
+                                           unsigned long long &first, uint32_t &len, uint32_t &hioff) const {
+        constexpr int CHUNK = KbCfg<KW>::CHUNK;
+        uint32_t m = 0;
+        if (plan.n_pass > 1) {                                  // largest m with ppref[m] <= r
+            uint32_t lo = 0, hi = plan.n_pass;
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ppref[mid] <= r) lo = mid; else hi = mid; }
+            m = lo;
+        }
+        const uint32_t j = r - ppref[m];                        // chunk of the bin inside pass m
+        const unsigned long long row = (prow[m] + j) * plan.off_stride;
+        const uint32_t r0 = s.chunk_off[row + f], r1 = s.chunk_off[row + f + 1];
+        len = r1 - r0;
+        const unsigned long long cs = pent[m] + (unsigned long long)j * CHUNK;      // first entry of the chunk
+        if constexpr (KW == 2) {                                // wide: word index of the run's h words; the hi words follow the chunk's h words
+            const unsigned long long left = pend[m] - cs;
+            hioff = (uint32_t)(left < (unsigned long long)CHUNK ? left : (unsigned long long)CHUNK);
+            first = 2 * cs + r0;
+        } else { hioff = 0; first = cs + r0; }
+    }
+};
+
 // count += 1 at LDS slot sl for the lanes with `hit` (the whole wave calls it together).  AGG: when every hit lane names
 // the SAME slot -- a key of enormous multiplicity: a homopolymer k-mer took 1.4 % of all windows of a repeat-rich genome, all
 // of them in one workgroup -- one lane adds the lot instead of 64 adds serialising on one LDS address (kernel C 14.6 -> 10.2
 // ms there, pass 24.8 -> 20.4 ms).  The test costs every wave ~8 instructions per key (+3 % on the kernel for a uniform
-// genome), so it lives in its own instantiation of the kernel (VAR 2).  kb_scan1_kernel reports a skewed coarse histogram
-// (totals[7]) and the host launches VAR 2 for the passes that FOLLOW a skewed one (a sample is many passes; launching both
-// instantiations and letting the device pick cost 0.08 ms per pass for 131 K workgroups that return at once).
+// genome), so it lives in its own instantiation of the kernel (VAR 2), launched when a pending pass reported a skewed coarse
+// histogram (totals[7], kb_scan1_kernel) -- known before kernel C runs, since C is deferred.
 template <bool AGG>
 __device__ __forceinline__ void kb_count_hits(uint32_t *tcnt, uint32_t sl, bool hit) {
     if constexpr (AGG) {
@@ -845,17 +610,12 @@ __device__ __forceinline__ void kb_count_hits(uint32_t *tcnt, uint32_t sl, bool 
     if (hit) atomicAdd(&tcnt[sl], 1u);
 }
 
-// MODE_INSERT / MODE_FILTERED: bucket slice staged in LDS.
-// MODE_REPLAY: only buckets flagged in s.failed, inserted through the global
-// atomic path into table t (which the host has grown since the failed pass;
-// `old_plan` is the plan the partition was built with).
 // narrow keys, one key: linear probing in the LDS slice from slot `sl`
 template <int MODE>
 __device__ __forceinline__ void kb_probe_narrow(uint64_t *tlo, uint32_t *tcnt, uint32_t bmask, uint64_t klo, uint32_t sl,
                                                 uint32_t &claimed, bool &failed) {
     // FOUR slots per iteration, their reads in flight together: a wave runs as many iterations as its longest probe, and
-    // every iteration costs scalar exec-mask bookkeeping on the CU's one scalar unit (round 2: the one-slot loop was 40 %
-    // of the super-k-mer bucket kernel's scalar instructions)
+    // every iteration costs scalar exec-mask bookkeeping on the CU's one scalar unit
     for (uint32_t n = 0; n <= bmask;) {
         uint64_t c[4];
 #pragma unroll
@@ -917,22 +677,21 @@ __device__ __forceinline__ void kb_probe_wide_wave(uint64_t *tlo, uint64_t *thi,
     }
 }
 
-// VAR 0: every lane probes its key in a loop (a wave pays the longest probe of its
-// 64 lanes for every key).  VAR 1 (INSERT / FILTERED): the first KB_C_LA slots of
-// the probe sequence are read at once and resolved in straight-line code; the keys
-// that need more go to a wave-private queue in LDS (ballot + mbcnt, no atomics, no
-// barrier) and are probed densely, one per lane, after the batch.  Measured on the
-// bench pass: kernel C 7.6 -> 6.5 ms at k = 31, 16.0 -> 12.7 ms at k = 63.
+// The first KB_C_LA slots of every probe sequence are read at once and resolved in straight-line code (a wave pays the
+// longest probe of its 64 lanes for every key it probes in a loop); the keys that need more go to a wave-private queue
+// in LDS (ballot + mbcnt, no atomics, no barrier) and are probed densely, one per lane, after the batch.  Measured on
+// the bench pass: kernel C 7.6 -> 6.5 ms at k = 31, 16.0 -> 12.7 ms at k = 63.
+// VAR 1: the default.  VAR 2: + wave-aggregated adds and heavy-bucket listing (skewed input).
 #ifndef KB_C_LA
-#define KB_C_LA    2                   // VAR 1: slots of the probe sequence read up front
+#define KB_C_LA    2                   // slots of the probe sequence read up front
 #endif
-#define KB_C_QCAPK(KW) (((KW) == 2 ? KB_C_WQ_W : 128) * (KB_C_CT(KW) / 64))   // VAR 1: queue entries per workgroup
-#define KB_C_QEXTRA(VAR, KW) ((VAR) ? (KB_C_QCAPK(KW) * ((KW) == 2 ? 18 : 10) + 16 + (KB_C_RUNS + 4) * 4) : 0)   // LDS bytes VAR 1 adds
+#define KB_C_QCAPK(KW) (((KW) == 2 ? KB_C_WQ_W : 128) * (KB_C_CT(KW) / 64))   // queue entries per workgroup
+#define KB_C_LDS(KW, BB) (((size_t)8 * (KW) + 4) * ((size_t)1 << (BB)) + (2 + 32 + KB_C_RUNS) * 4 + (size_t)KB_C_RUNS * 8 + ((KW) == 2 ? (size_t)KB_C_RUNS * 4 : 0) \
+                          + KB_C_QCAPK(KW) * ((KW) == 2 ? 18 : 10) + 16 + (KB_C_RUNS + 4) * 4 + KB_RI_LDS_BYTES)
 template <int KW, int MODE, int VAR>
 __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_C_WPE, KB_C_WPE))) void kb_bucket_kernel(
     KbPlan plan, KbScratch s, KdfTable t, KdfCtl *ctl, int table_nonempty)
 {
-    constexpr int CHUNK = KbCfg<KW>::CHUNK;
     constexpr uint32_t CT = KB_C_CT(KW), QCAP = KB_C_QCAPK(KW);      // threads and queue entries per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t B = 1u << plan.bucket_bits;
@@ -943,85 +702,64 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
     uint32_t *wsum = tcnt + B + 2;                            // [32]
     uint32_t *run_pref = wsum + 32;                           // [KB_C_RUNS] exclusive prefix of run lengths
     unsigned long long *run_first = (unsigned long long *)(run_pref + KB_C_RUNS);   // [KB_C_RUNS] (B + 34 + KB_C_RUNS is even: 8-aligned)
-    uint32_t *run_hi = (uint32_t *)(run_first + KB_C_RUNS);   // [KB_C_RUNS] wide keys only: distance (words) from a run's lo words to its hi words
-    uint64_t *qk = (uint64_t *)(run_hi + (KW == 2 ? KB_C_RUNS : 0));   // [QCAP] VAR 1: keys whose probe goes past the lookahead (per wave: QCAP / 8)
+    uint32_t *run_hi = (uint32_t *)(run_first + KB_C_RUNS);   // [KB_C_RUNS] wide keys only: distance (words) from a run's h words to its hi words
+    uint64_t *qk = (uint64_t *)(run_hi + (KW == 2 ? KB_C_RUNS : 0));   // [QCAP] keys whose probe goes past the lookahead (per wave: QCAP / waves)
     uint16_t *qs = (uint16_t *)(qk + QCAP);              // [QCAP] slot to go on from
     uint64_t *qk2 = (uint64_t *)((uint32_t *)(qs + QCAP) + 2 + KB_C_RUNS + 4);   // [QCAP] wide keys: hi words of the queued keys
-    uint32_t *rpw = (uint32_t *)(qs + QCAP) + 2;                                  // [KB_C_RUNS + 4] VAR >= 1: run_pref shifted by one, padded with `total`
+    uint32_t *rpw = (uint32_t *)(qs + QCAP) + 2;                                  // [KB_C_RUNS + 4] run_pref shifted by one, padded with `total`
+    KbRunIndex ri;
+    ri.bind((char *)(qk2 + (KW == 2 ? QCAP : 0)));
 
-    // `plan` describes the table the partition was built for.  In MODE_REPLAY
-    // that is the OLD geometry (the host has grown the table since) and `t` is
-    // the new table.
     // Workgroups are dealt to the 8 XCDs round robin by blockIdx, and each XCD has its own L2.  Neighbouring buckets
     // (f, f + 1 of one coarse bin) read neighbouring runs of the same chunks -- they share the cache line at every run
     // boundary and the lines of the offset table -- so an XCD takes a contiguous eighth of the buckets, in order.
-    if (s.failed_flag[0]) return;                              // the partition is not usable (a cell overflowed / the stream changed): the host knows
+    if (s.failed_flag[0]) return;                              // a partition is not usable (the stream changed under it): the host knows
 
-    if (plan.cells && MODE != KB_MODE_REPLAY && blockIdx.x == 0 && threadIdx.x == 0 && s.totals[5])
-        atomicAdd(&ctl->windows[0], s.totals[5]);              // the valid windows the cell scatter counted
     const uint32_t nbk = gridDim.x;
-    const uint64_t bucket = (nbk & 7) ? blockIdx.x : (uint64_t)(blockIdx.x & 7) * (nbk >> 3) + (blockIdx.x >> 3);   // table bucket of `plan`
+    const uint64_t bucket = (nbk & 7) ? blockIdx.x : (uint64_t)(blockIdx.x & 7) * (nbk >> 3) + (blockIdx.x >> 3);   // table bucket
     const uint64_t pb = bucket >> plan.sub_bits;              // partition bucket holding its entries
     const uint32_t c = (uint32_t)(pb >> plan.c2), f = (uint32_t)(pb & ((1u << plan.c2) - 1));
-    if constexpr (MODE == KB_MODE_REPLAY) {
-        if (!((s.failed[bucket >> 5] >> (bucket & 31)) & 1)) return;
-    }
     const uint64_t slot0 = bucket << plan.bucket_bits;        // first slot of the bucket in HBM
     if (threadIdx.x == 0) { sh_failed = 0; sh_claimed = 0; }
-    if constexpr (MODE != KB_MODE_REPLAY) {
-        if (table_nonempty) {
-            for (uint32_t i = threadIdx.x; i < B; i += CT) {
-                tlo[i] = t.lo[slot0 + i];
-                if constexpr (KW == 2) thi[i] = t.hi[slot0 + i];
-                tcnt[i] = t.cnt[slot0 + i];
-            }
-        } else {
-            // two slots per lane and step: 16-byte LDS writes (B is even, the arrays are 16-byte aligned)
-            const ulonglong2 e2 = {KDF_EMPTY, KDF_EMPTY};
-            for (uint32_t i = threadIdx.x; i < B / 2; i += CT) {
-                ((ulonglong2 *)tlo)[i] = e2;
-                if constexpr (KW == 2) ((ulonglong2 *)thi)[i] = e2;
-                ((uint2 *)tcnt)[i] = uint2{0u, 0u};
-            }
+    if (table_nonempty) {
+        for (uint32_t i = threadIdx.x; i < B; i += CT) {
+            tlo[i] = t.lo[slot0 + i];
+            if constexpr (KW == 2) thi[i] = t.hi[slot0 + i];
+            tcnt[i] = t.cnt[slot0 + i];
+        }
+    } else {
+        // two slots per lane and step: 16-byte LDS writes (B is even, the arrays are 16-byte aligned)
+        const ulonglong2 e2 = {KDF_EMPTY, KDF_EMPTY};
+        for (uint32_t i = threadIdx.x; i < B / 2; i += CT) {
+            ((ulonglong2 *)tlo)[i] = e2;
+            if constexpr (KW == 2) ((ulonglong2 *)thi)[i] = e2;
+            ((uint2 *)tcnt)[i] = uint2{0u, 0u};
         }
     }
-    __syncthreads();
+    const uint32_t n_runs = ri.setup(plan, s, c);             // (barrier inside)
 
     constexpr uint32_t WQ = QCAP / (CT / 64);
     uint64_t *wqk = qk + (threadIdx.x >> 6) * WQ;
     uint64_t *wqk2 = qk2 + (threadIdx.x >> 6) * WQ;
     uint16_t *wqs = qs + (threadIdx.x >> 6) * WQ;
     uint32_t wq_n = 0;
-    const unsigned long long j0 = s.chunk_first[c], j1 = s.chunk_first[c + 1];
-    const unsigned long long bstart = s.bin_start[c], bend = s.bin_start[c + 1];
     const uint32_t bmask = B - 1;
+    const uint32_t hsh_r = 64 - plan.log2cap;                 // home slot = h >> hsh_r (binned tables have no hash_shift)
     uint32_t claimed = 0;
     bool failed = false;
-    // Runs of this bucket: one per chunk of its coarse bin.  Their bounds are
+    // Runs of this bucket: one per chunk of its coarse bin and pending pass.  Their bounds are
     // fetched by all threads at once (one global latency, not one per run) and
     // laid out in LDS as a flat work list; threads then take entries round
     // robin, so every lane is busy whatever the run lengths are.
-    for (unsigned long long jb = j0; jb < j1; jb += KB_C_RUNS) {
+    for (uint32_t rb = 0; rb < n_runs; rb += KB_C_RUNS) {
         uint32_t len = 0, hioff = 0; unsigned long long first = 0;
-        {
-            const unsigned long long j = jb + threadIdx.x;
-            if (threadIdx.x < KB_C_RUNS && j < j1) {
-                const uint32_t r0 = s.chunk_off[j * plan.off_stride + f], r1 = s.chunk_off[j * plan.off_stride + f + 1];
-                len = r1 - r0;
-                const unsigned long long cs = bstart + (j - j0) * (unsigned long long)(plan.cells ? plan.cell_stride : (uint32_t)CHUNK);      // first entry of the chunk
-                if constexpr (KW == 2) {                      // wide: word index of the run's lo words; the hi words follow the chunk's lo words
-                    const unsigned long long left = bend - cs;
-                    hioff = (uint32_t)(left < (unsigned long long)CHUNK ? left : (unsigned long long)CHUNK);
-                    first = 2 * cs + r0;
-                } else first = cs + r0;
-            }
-        }
+        if (threadIdx.x < KB_C_RUNS && rb + threadIdx.x < n_runs) ri.locate<KW>(plan, s, f, rb + threadIdx.x, first, len, hioff);
         uint32_t total = 0;
         const uint32_t ex = kb_block_exscan(len, wsum, &total);
         if constexpr (VAR == 2 && KW == 1 && MODE == KB_MODE_INSERT) {
             // A heavy bucket (a few keys of enormous multiplicity) is not for ONE workgroup: it is left untouched here, as
             // a failed bucket would be, and KB_HV_SLICES workgroups share its runs afterwards (kb_heavy_slice_kernel).
-            if (jb == j0 && total > KB_C_HEAVY && s.hv_ctr && !plan.cells && plan.sub_bits == 0 && plan.bucket_bits == 12) {   // (the host launches the heavy kernels under the same conditions)
+            if (rb == 0 && total > KB_C_HEAVY && s.hv_ctr && plan.sub_bits == 0 && plan.bucket_bits == 12) {   // (the host launches the heavy kernels under the same conditions)
                 if (threadIdx.x == 0) {
                     const uint32_t idx = atomicAdd(&s.hv_ctr[0], 1u);
                     sh_failed = idx;                          // (borrowed as a broadcast word; restored below)
@@ -1040,24 +778,21 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
             }
         }
         if (threadIdx.x < KB_C_RUNS) { run_pref[threadIdx.x] = ex; run_first[threadIdx.x] = first; if constexpr (KW == 2) run_hi[threadIdx.x] = hioff; }
-        if constexpr (VAR >= 1) {
-            if (threadIdx.x < KB_C_RUNS + 3) rpw[threadIdx.x + 1] = ex;     // threads past the last run hold ex == total
-            if (threadIdx.x == 0) rpw[0] = 0;
-        }
+        if (threadIdx.x < KB_C_RUNS + 3) rpw[threadIdx.x + 1] = ex;     // threads past the last run hold ex == total
+        if (threadIdx.x == 0) rpw[0] = 0;
         __syncthreads();
-        const uint32_t nruns = (uint32_t)((j1 - jb) < (unsigned long long)KB_C_RUNS ? (j1 - jb) : (unsigned long long)KB_C_RUNS);
-        constexpr int EPB = VAR >= 1 ? (KW == 2 ? KB_C_EPB_W : KB_C_EPB_N) : 12;    // entries per thread per batch: EPB (x KW) loads in flight per lane
+        const uint32_t nruns = n_runs - rb < (uint32_t)KB_C_RUNS ? n_runs - rb : (uint32_t)KB_C_RUNS;
+        constexpr int EPB = KW == 2 ? KB_C_EPB_W : KB_C_EPB_N;    // entries per thread per batch: EPB (x KW) loads in flight per lane
         // (ei * inv_total) >> 32 ~= ei * nruns / total
         const unsigned long long inv_total = total ? (((unsigned long long)nruns << 32) / total) : 0;
         for (uint32_t e0 = 0; e0 < total; e0 += CT * EPB) {   // wave-uniform trip count
           uint64_t bklo[EPB], bkhi[KW == 2 ? EPB : 1];
-          // Flat index of this thread's q-th entry of the batch.  Narrow keys (VAR 1): a WAVE takes 64 * EPB
+          // Flat index of this thread's q-th entry of the batch.  Narrow keys: a WAVE takes 64 * EPB
           // consecutive entries, lane l's q-th entry is wbase + 64 q -- one load instruction still reads 64
           // consecutive entries, and a lane's consecutive entries are about one run (64 entries) further on,
-          // so the run is searched once per batch and then only advanced.  The per-entry search was a
-          // quarter of this kernel's vector instructions, and the kernel is bound by those (6.45 -> 6.2 ms).
+          // so the run is searched once per batch and then only advanced.
           // Wide keys have 16-entry runs (four runs per step): they keep the per-entry windowed search.
-          constexpr bool WAVE_SPANS = VAR >= 1 && KW == 1;
+          constexpr bool WAVE_SPANS = KW == 1;
           const uint32_t wbase = WAVE_SPANS ? e0 + (threadIdx.x >> 6) * (64 * EPB) + (threadIdx.x & 63) : e0 + threadIdx.x;
           constexpr uint32_t QSTEP = WAVE_SPANS ? 64u : (uint32_t)CT;      // flat-index distance between a thread's consecutive entries
           if constexpr (WAVE_SPANS) {
@@ -1087,11 +822,10 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
                         do { ++cr; cpf = cnx; cnx = rpw[cr + 2]; } while (ei >= cnx);
                         cf = run_first[cr];
                     }
-                    bklo[q] = s.ent_lo[cf + (ei - cpf)];
+                    bklo[q] = s.ent[cf + (ei - cpf)];
                 }
             }
-          } else
-          if constexpr (VAR >= 1) {
+          } else {
             // windowed search: the guess is within a run or two of the answer, so read
             // run_pref[guess-1 .. guess+2] for four entries at once and count -- two LDS
             // round trips per four entries instead of a dependent probe chain per entry
@@ -1141,30 +875,13 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
                     bklo[q0 + g] = 0; if constexpr (KW == 2) bkhi[q0 + g] = 0;
                     if (ei < total) {
                         const unsigned long long src = rf[g] + (ei - pf4[g]);
-                        bklo[q0 + g] = s.ent_lo[src];
-                        if constexpr (KW == 2) bkhi[q0 + g] = s.ent_lo[src + run_hi[lo4[g]]];
+                        bklo[q0 + g] = s.ent[src];
+                        if constexpr (KW == 2) bkhi[q0 + g] = s.ent[src + run_hi[lo4[g]]];
                     }
                 }
             }
-          } else {
-#pragma unroll
-          for (int q = 0; q < EPB; ++q) {
-            const uint32_t ei = e0 + q * CT + threadIdx.x;
-            bklo[q] = 0; if constexpr (KW == 2) bkhi[q] = 0;
-            if (ei < total) {
-                // largest r with run_pref[r] <= ei.  Runs of a bucket have nearly equal
-                // lengths (hash-uniform), so interpolate and correct by a step or two.
-                uint32_t lo_ = (uint32_t)(((unsigned long long)ei * inv_total) >> 32);
-                if (lo_ >= nruns) lo_ = nruns - 1;
-                while (run_pref[lo_] > ei) --lo_;
-                while (lo_ + 1 < nruns && run_pref[lo_ + 1] <= ei) ++lo_;
-                const unsigned long long src = run_first[lo_] + (ei - run_pref[lo_]);
-                if constexpr (KW == 2) { bklo[q] = s.ent_lo[src]; bkhi[q] = s.ent_lo[src + run_hi[lo_]]; }
-                else bklo[q] = s.ent_lo[src];
-            }
           }
-          }
-          if constexpr (VAR >= 1 && KW == 1 && MODE != KB_MODE_REPLAY) {
+          if constexpr (KW == 1) {
             constexpr int G = 4;                                 // keys resolved together: G * KB_C_LA LDS reads in flight
 #pragma unroll
             for (int q0 = 0; q0 < EPB; q0 += G) {
@@ -1173,7 +890,7 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     const uint32_t ei = wbase + QSTEP * (q0 + g);
-                    const uint64_t home = kdf_hash(bklo[q0 + g], 0) >> (64 - plan.log2cap);
+                    const uint64_t home = bklo[q0 + g] >> hsh_r;                  // the entry is the hash
                     td[g] = ei < total && !(plan.sub_bits && (home >> plan.bucket_bits) != bucket);
                     sl0[g] = (uint32_t)home & bmask;
 #pragma unroll
@@ -1231,7 +948,7 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
                     kb_probe_narrow<MODE>(tlo, tcnt, bmask, wqk[i], wqs[i], claimed, failed);
                 wq_n = 0;
             }
-          } else if constexpr (VAR >= 1 && KW == 2 && MODE != KB_MODE_REPLAY) {
+          } else {
             // Two-word keys, same scheme.  The hi words of the lookahead slots are read BEFORE their lo
             // words (LDS serves a wave's instructions in order and a claimer writes lo before the final
             // hi), so a slot whose hi reads as the key's hi without PENDING has its lo in place.  A slot
@@ -1245,7 +962,7 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     const uint32_t ei = wbase + QSTEP * (q0 + g);
-                    const uint64_t home = kdf_hash(bklo[q0 + g], bkhi[q0 + g]) >> (64 - plan.log2cap);
+                    const uint64_t home = bklo[q0 + g] >> hsh_r;                  // the entry's first word is the hash
                     td[g] = ei < total && !(plan.sub_bits && (home >> plan.bucket_bits) != bucket);
                     sl0[g] = (uint32_t)home & bmask;
 #pragma unroll
@@ -1313,48 +1030,13 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
                 }
                 wq_n = 0;
             }
-          } else {
-#pragma unroll
-          for (int q = 0; q < EPB; ++q) {
-            const uint32_t ei = e0 + q * CT + threadIdx.x;
-            bool todo = ei < total;
-            const uint64_t klo = bklo[q], khi = KW == 2 ? bkhi[q] : 0;
-            const uint64_t h = kdf_hash(klo, khi);
-            const uint64_t home = h >> (64 - plan.log2cap);
-            if (plan.sub_bits && (home >> plan.bucket_bits) != bucket) todo = false;   // sibling bucket's entry
-            if constexpr (MODE == KB_MODE_REPLAY) {
-                const uint64_t slot = kdf_home(t, h);
-                bool ok = true;
-                if constexpr (KW == 1) { if (todo) ok = kdf_add_narrow<true>(t, klo, 1u, slot, t.lo[slot], claimed); }
-                else ok = kdf_add_wide<true>(t, todo, klo, khi, 1u, slot, claimed);
-                if (!ok) failed = true;
-                continue;
-            }
-            if constexpr (KW == 1) {
-                if (!todo) continue;
-                if (plan.dbg & 1) { claimed += (uint32_t)(klo >> 61); continue; }
-                kb_probe_narrow<MODE>(tlo, tcnt, bmask, klo, (uint32_t)home & bmask, claimed, failed);
-            } else {
-                // wide: claim hi with PENDING, publish lo, then the final hi (all in LDS).
-                // No lane waits inside a divergent loop (kdf_device.h): a lane that meets
-                // a PENDING slot retries in the next pass of a wave-uniform loop.
-                kb_probe_wide_wave<MODE>(tlo, thi, tcnt, bmask, todo, klo, khi, (uint32_t)home & bmask, claimed, failed);
-            }
           }
         }
-          }
         __syncthreads();       // run_pref / run_first are rewritten by the next round
     }
     if (failed) atomicOr(&sh_failed, 1u);
     if (claimed) atomicAdd(&sh_claimed, claimed);
     __syncthreads();
-    if constexpr (MODE == KB_MODE_REPLAY) {
-        if (threadIdx.x == 0) {
-            if (sh_failed) atomicOr(&ctl->error, 1u);
-            if (sh_claimed) atomicAdd(&ctl->distinct[(bucket % KDF_SHARDS) * 16], (unsigned long long)sh_claimed);
-        }
-        return;
-    }
     if (sh_failed) {
         // leave the bucket as it was in HBM; flag it for replay.  A lazily
         // cleared table holds garbage there: write an empty slice instead.
@@ -1371,8 +1053,7 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
         }
         return;
     }
-    if (plan.dbg & 4) return;
-    // LDS counts were advanced with plain (wrapping, non-returning) adds.  A pass
+    // LDS counts were advanced with plain (wrapping, non-returning) adds.  A flush
     // adds fewer than 2^32 to a slot, so a slot wrapped iff its new value is below
     // the value it had in HBM: saturate those (Jellyfish's 4-byte counter).
     // two slots per lane and step: 16-byte LDS reads and HBM stores for the keys, 8-byte ones for the counts
@@ -1382,21 +1063,55 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
             ((ulonglong2 *)(t.lo + slot0))[i] = ((const ulonglong2 *)tlo)[i];
             if constexpr (KW == 2) ((ulonglong2 *)(t.hi + slot0))[i] = ((const ulonglong2 *)thi)[i];
         }
-        uint2 c = ((const uint2 *)tcnt)[i];
+        uint2 c2 = ((const uint2 *)tcnt)[i];
         if (table_nonempty) {
             const uint2 o = ((const uint2 *)(t.cnt + slot0))[i];
-            if (c.x < o.x) c.x = 0xFFFFFFFFu;
-            if (c.y < o.y) c.y = 0xFFFFFFFFu;
+            if (c2.x < o.x) c2.x = 0xFFFFFFFFu;
+            if (c2.y < o.y) c2.y = 0xFFFFFFFFu;
         }
-        ((uint2 *)(t.cnt + slot0))[i] = c;
+        ((uint2 *)(t.cnt + slot0))[i] = c2;
     }
     if (threadIdx.x == 0 && sh_claimed)
         atomicAdd(&ctl->distinct[(bucket % KDF_SHARDS) * 16], (unsigned long long)sh_claimed);
 }
 
+// Replay of the buckets kernel C flagged (s.failed): their entries go through the global-atomic path into table t,
+// which the host has grown since.  `plan` is the geometry the failed flush ran with (bucket numbering of s.failed).
+template <int KW>
+__global__ __launch_bounds__(256) void kb_replay_kernel(KbPlan plan, KbScratch s, KdfTable t, KdfCtl *ctl) {
+    __shared__ __attribute__((aligned(16))) char rmem[KB_RI_LDS_BYTES];
+    const uint64_t bucket = blockIdx.x;
+    if (!((s.failed[bucket >> 5] >> (bucket & 31)) & 1)) return;
+    const uint64_t pb = bucket >> plan.sub_bits;
+    const uint32_t c = (uint32_t)(pb >> plan.c2), f = (uint32_t)(pb & ((1u << plan.c2) - 1));
+    KbRunIndex ri; ri.bind(rmem);
+    const uint32_t n_runs = ri.setup(plan, s, c);
+    const uint32_t hsh_r = 64 - plan.log2cap;
+    uint32_t claimed = 0; bool failed = false;
+    for (uint32_t r = 0; r < n_runs; ++r) {
+        unsigned long long first; uint32_t len, hioff;
+        ri.locate<KW>(plan, s, f, r, first, len, hioff);
+        for (uint32_t i0 = 0; i0 < len; i0 += 256) {           // wave-uniform trip count (the wide claim protocol needs whole waves)
+            const uint32_t i = i0 + threadIdx.x;
+            bool todo = i < len;
+            const uint64_t klo = todo ? s.ent[first + i] : 0, khi = (KW == 2 && todo) ? s.ent[first + i + hioff] : 0;
+            if (plan.sub_bits && ((klo >> hsh_r) >> plan.bucket_bits) != bucket) todo = false;   // sibling bucket's entry
+            const uint64_t slot = kdf_home(t, klo);
+            bool ok = true;
+            if constexpr (KW == 1) { if (todo) ok = kdf_add_narrow<true>(t, klo, 1u, slot, t.lo[slot], claimed); }
+            else ok = kdf_add_wide<true>(t, todo, klo, khi, 1u, slot, claimed);
+            if (!ok) failed = true;
+        }
+    }
+    if (failed) atomicOr(&ctl->error, 1u);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) claimed += __shfl_down(claimed, o);
+    if ((threadIdx.x & 63) == 0 && claimed) atomicAdd(&ctl->distinct[(bucket % KDF_SHARDS) * 16], (unsigned long long)claimed);
+}
+
 
 // ---------------------------------------------------------------------------
-// Heavy buckets of a skewed pass (narrow keys, insert mode; see kb_count_hits).  kb_bucket_kernel<.., VAR 2> lists the
+// Heavy buckets of a skewed flush (narrow keys, insert mode; see kb_count_hits).  kb_bucket_kernel<.., VAR 2> lists the
 // buckets whose first 256 runs alone hold more than KB_C_HEAVY entries and leaves them untouched.  Here KB_HV_SLICES
 // workgroups share such a bucket's runs (run r to slice r % KB_HV_SLICES), each counting into a PRIVATE empty LDS table,
 // and stage their distinct (key, count) pairs; kb_heavy_combine_kernel then folds the staged pairs into the bucket the way
@@ -1404,7 +1119,6 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
 // Measured on the repeat-rich 100 Mbp genome (38 heavy buckets, the heaviest 15.9 M entries): kernel C 10.0 -> 6.2 ms, the
 // pass 20.1 -> 16.0 ms.
 __global__ __launch_bounds__(256) void kb_heavy_slice_kernel(KbPlan plan, KbScratch s) {
-    constexpr int CHUNK = KbCfg<1>::CHUNK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (!s.hv_ctr || s.failed_flag[0]) return;
     const uint32_t nh = min(s.hv_ctr[0], KB_HV_MAX), h = blockIdx.y, slice = blockIdx.x;
@@ -1412,19 +1126,20 @@ __global__ __launch_bounds__(256) void kb_heavy_slice_kernel(KbPlan plan, KbScra
     const uint32_t B = 1u << plan.bucket_bits, bmask = B - 1;
     uint64_t *tlo = (uint64_t *)smem;
     uint32_t *tcnt = (uint32_t *)(smem + (size_t)B * 8);
+    KbRunIndex ri; ri.bind(smem + (size_t)B * 12);
     __shared__ uint32_t sh_fail, sh_n, sh_base;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     for (uint32_t i = tid; i < B; i += 256) { tlo[i] = KDF_EMPTY; tcnt[i] = 0; }
     if (tid == 0) { sh_fail = 0; sh_n = 0; }
-    __syncthreads();
     const uint64_t bucket = s.hv_bucket[h];
     const uint32_t c = (uint32_t)(bucket >> plan.c2), f = (uint32_t)(bucket & ((1u << plan.c2) - 1));
-    const unsigned long long j0 = s.chunk_first[c], j1 = s.chunk_first[c + 1], bstart = s.bin_start[c];
+    const uint32_t n_runs = ri.setup(plan, s, c);               // (barrier inside)
+    const uint32_t hsh_r = 64 - plan.log2cap;
     uint32_t claimed = 0; bool failed = false;
-    for (unsigned long long j = j0 + slice; j < j1; j += KB_HV_SLICES) {
-        const uint32_t r0 = s.chunk_off[j * plan.off_stride + f], r1 = s.chunk_off[j * plan.off_stride + f + 1];
-        const uint64_t *ent = s.ent_lo + bstart + (j - j0) * (unsigned long long)CHUNK + r0;
-        const uint32_t n = r1 - r0;
+    for (uint32_t r = slice; r < n_runs; r += KB_HV_SLICES) {
+        unsigned long long first; uint32_t n, hioff;
+        ri.locate<1>(plan, s, f, r, first, n, hioff);
+        const uint64_t *ent = s.ent + first;
         constexpr int U = 8;                                       // entries per thread in flight: one workgroup has to cover the HBM latency alone
         for (uint32_t i0 = 0; i0 < n; i0 += 256 * U) {             // whole waves: the hit counting is a wave operation
             uint64_t keys[U];
@@ -1435,7 +1150,7 @@ __global__ __launch_bounds__(256) void kb_heavy_slice_kernel(KbPlan plan, KbScra
                 if (i0 + u * 256 >= n) break;                      // (uniform)
                 const bool todo = i0 + u * 256 + tid < n;
                 const uint64_t key = keys[u];
-                const uint32_t sl = (uint32_t)(kdf_hash(key, 0) >> (64 - plan.log2cap)) & bmask;
+                const uint32_t sl = (uint32_t)(key >> hsh_r) & bmask;
                 const bool hit = todo && tlo[sl] == key;           // the heavy key sits in its home slot after its first insertion
                 kb_count_hits<true>(tcnt, sl, hit);
                 if (todo && !hit) {
@@ -1482,7 +1197,7 @@ __global__ __launch_bounds__(256) void kb_heavy_combine_kernel(KbPlan plan, KbSc
     if (!s.hv_ctr || s.failed_flag[0]) return;
     const uint32_t nh = min(s.hv_ctr[0], KB_HV_MAX), h = blockIdx.x;
     if (h >= nh) return;
-    if (h == 0 && threadIdx.x == 0) s.totals[4] = s.hv_ctr[0];     // (statistics: heavy buckets of this pass; the first KB_HV_MAX were split)
+    if (h == 0 && threadIdx.x == 0) s.totals[4] = s.hv_ctr[0];     // (statistics: heavy buckets of this flush; the first KB_HV_MAX were split)
     const uint32_t B = 1u << plan.bucket_bits, bmask = B - 1;
     uint64_t *tlo = (uint64_t *)smem;
     uint32_t *tcnt = (uint32_t *)(smem + (size_t)B * 8);
@@ -1499,11 +1214,12 @@ __global__ __launch_bounds__(256) void kb_heavy_combine_kernel(KbPlan plan, KbSc
     const size_t room = (size_t)KB_HV_SLICES << plan.bucket_bits;
     const uint64_t *ik = s.hv_key + (size_t)h * room; const uint32_t *ic = s.hv_cnt + (size_t)h * room;
     const uint32_t n = s.hv_n[h];
+    const uint32_t hsh_r = 64 - plan.log2cap;
     uint32_t claimed = 0; bool failed = false;
     if (!sh_fail)
         for (uint32_t i = tid; i < n; i += 256) {
             const uint64_t key = ik[i]; const uint32_t add = ic[i];
-            uint32_t at = (uint32_t)(kdf_hash(key, 0) >> (64 - plan.log2cap)) & bmask; bool done = false;
+            uint32_t at = (uint32_t)(key >> hsh_r) & bmask; bool done = false;
             for (uint32_t p_ = 0; p_ <= bmask && !done; ++p_) {
                 uint64_t cur = tlo[at];
                 if (cur == KDF_EMPTY) {
@@ -1526,3 +1242,21 @@ __global__ __launch_bounds__(256) void kb_heavy_combine_kernel(KbPlan plan, KbSc
     if (tid == 0 && sh_claimed) atomicAdd(&ctl->distinct[(bucket % KDF_SHARDS) * 16], (unsigned long long)sh_claimed);
 }
 
+// ---------------------------------------------------------------------------
+// L1 of the deferral: small batches are first CONCATENATED, packed as they arrive (2.25 bits per position), in a pending
+// stream; the partition kernels then run over ~2^30 positions at a time whatever the caller's batch size is.  A batch
+// starts on a tile boundary of the pending stream; the bits of its last mask word past n_bases read "invalid" whatever the
+// source holds there, and the padded tail kdf_stream_words() promises (2 mask words of ones, 4 packed words) follows it.
+__global__ __launch_bounds__(256) void kb_append_kernel(uint64_t *__restrict__ dp, uint64_t *__restrict__ dm,
+                                                        const uint64_t *__restrict__ sp, const uint64_t *__restrict__ sm,
+                                                        uint64_t n_bases) {
+    const uint64_t n_tiles = (n_bases + 63) >> 6;
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < 2 * n_tiles) dp[i] = i < ((n_bases + 31) >> 5) ? sp[i] : 0ull;
+    else if (i < 2 * n_tiles + 4) dp[i] = 0ull;
+    if (i < n_tiles) {
+        uint64_t m = sm[i];
+        if (i == n_tiles - 1 && (n_bases & 63)) m |= ~0ull << (n_bases & 63);
+        dm[i] = m;
+    } else if (i < n_tiles + 2) dm[i] = ~0ull;
+}

@@ -12,20 +12,43 @@
 
 // ---------------------------------------------------------------------------
 // hash: fold the high half into the low half, then ONE 64-bit multiply by an odd
-// constant (Fibonacci hashing).  Only the TOP bits of the result are ever used
-// (bucket = top bits, home slot = the bits below), and those depend on every
-// input bit.  A 64-bit multiply is ~8 quarter-rate VALU instructions on CDNA4
-// and the hash is evaluated several times per k-mer along the binned pipeline,
-// so a second multiply is not free.  Bijective on 64 bits (xor-shift and odd
-// multiply are both invertible).
+// constant (Fibonacci hashing).  Only the TOP bits of the result are ever used for
+// addressing (bucket = top bits, home slot = the bits below), and those depend on
+// every input bit.  Bijective on 64 bits (xor-shift and odd multiply are both
+// invertible: kdf_unmix64).
+//
+// STORED FORM.  Because the hash is a bijection, the engine never carries a key
+// next to its hash: partition entries and table slots hold h = kdf_mix64(key) in
+// place of the key (wide keys: (h, hi) with h = kdf_hash(lo, hi); lo comes back as
+// kdf_unmix64(h) ^ rot(hi)), every stage takes its bits straight from h, and the
+// key is recovered only where it leaves the engine (dump / export).  A 64-bit
+// multiply is ~8 quarter-rate VALU instructions on CDNA4 and rounds 1-2 evaluated
+// it four times per window along the binned pipeline.
+//
+// KDF_EMPTY (all ones) must not be the stored form of a key: with this multiplier
+// kdf_unmix64(~0) = 0xfd54638d0fbbb8de, which is >= 2^62 (not a key for k <= 31)
+// and, read as a 32-mer, starts with T and ends with G -- its reverse complement
+// starts with C and is smaller, so it is not canonical either (k = 32).
+// (0x9E3779B97F4A7C15, used in rounds 1-2, maps a valid canonical 31-/32-mer there.)
+#define KDF_MIX_MUL     0x9FB21C651E98DF25ull
+#define KDF_MIX_MUL_INV 0x02ab9c720d1024adull   /* KDF_MIX_MUL * KDF_MIX_MUL_INV == 1 (mod 2^64) */
 __host__ __device__ __forceinline__ uint64_t kdf_mix64(uint64_t x) {
     x ^= x >> 32;
-    x *= 0x9E3779B97F4A7C15ull;
+    x *= KDF_MIX_MUL;
     return x;
 }
+__host__ __device__ __forceinline__ uint64_t kdf_unmix64(uint64_t h) {
+    h *= KDF_MIX_MUL_INV;
+    return h ^ (h >> 32);
+}
+// wide keys: rotate hi so that its used (low) bits land on lo's upper half
+__host__ __device__ __forceinline__ uint64_t kdf_rot_hi(uint64_t hi) { return (hi << 37) | (hi >> 27); }
 __host__ __device__ __forceinline__ uint64_t kdf_hash(uint64_t lo, uint64_t hi) {
-    // wide keys: rotate hi so that its used (low) bits land on lo's upper half
-    return kdf_mix64(lo ^ ((hi << 37) | (hi >> 27)));
+    return kdf_mix64(lo ^ kdf_rot_hi(hi));
+}
+// the low key word back from the stored form (hi = 0 for narrow keys)
+__host__ __device__ __forceinline__ uint64_t kdf_key_lo(uint64_t h, uint64_t hi) {
+    return kdf_unmix64(h) ^ kdf_rot_hi(hi);
 }
 
 // reverse the 32 two-bit groups of a 64-bit word
@@ -43,11 +66,12 @@ __host__ __device__ __forceinline__ uint64_t kdf_rev2(uint64_t x) {
 
 // ---------------------------------------------------------------------------
 // Table view.  Open addressing, SoA: lo[cap] (+ hi[cap] for wide keys) and
-// cnt[cap].  A key's home slot is the TOP log2cap bits of its hash; probing is
+// cnt[cap].  lo[] holds the STORED FORM h of the key (above), hi[] the key's high
+// word as it is.  A key's home slot is the TOP log2cap bits of h; probing is
 // linear and wraps inside the key's bucket of 2^bucket_bits slots, so a bucket
 // (keys + counts) is a self-contained unit that an LDS-staged kernel can own.
 struct KdfTable {
-    uint64_t *lo;
+    uint64_t *lo;          // stored form h (narrow: kdf_mix64(key); wide: kdf_hash(lo, hi))
     uint64_t *hi;          // nullptr for k <= 32
     uint32_t *cnt;
     uint32_t log2cap;
@@ -57,21 +81,6 @@ struct KdfTable {
     // one table is counted in several passes over the same stream.
     uint32_t key_parts;    // 0 or 1: everything
     uint32_t key_part;
-    // Minimizer-bucketed ("SK") layout, narrow keys only (kdf_sk.h): the BUCKET of a key is chosen by its minimizer
-    // (smallest canonical 12-mer under sk_order), so all k-mers of a minimizer-delimited read substring share a
-    // bucket; the slot inside the bucket still comes from the key's hash.  A key whose probe sequence finds neither
-    // itself nor an empty slot within KDF_SK_MAXPROBE slots lives in the overflow table (plain open addressing over
-    // the whole ovf array), so a minimizer that owns more distinct k-mers than a bucket holds is never an error.
-    uint32_t sk;           // 0: hash layout (bucket = top hash bits)
-    uint32_t k;            // k-mer length (SK lookups derive the minimizer from the key)
-    uint64_t *ovf_lo;
-    uint32_t *ovf_cnt;
-    uint32_t ovf_log2cap;
-    // Balanced minimizer -> bucket assignment (optional): the coarse bin is the top sk_c1 bits of the spread order
-    // value h, the bucket inside the bin is sk_assign[h] (dealt out by weight, kdf_sk.h sk_assign_kernel); without
-    // the table the bucket is simply the top bits of h.
-    uint32_t sk_c1, sk_c2;
-    const uint16_t *sk_assign;
     // Owner tables of the multi-GPU merge (option "hash_shift"): rank r of 2^w only ever sees keys whose top w hash
     // bits are r, so the home slot drops them -- the table is used over its whole length, and a dump that arrives in
     // the sender's slot order is still in this table's slot order.
@@ -98,67 +107,6 @@ __device__ __forceinline__ uint64_t kdf_home(const KdfTable &t, uint64_t h) {
     return (h << t.hshift) >> (64 - t.log2cap);
 }
 
-// ---- minimizer-bucketed layout ------------------------------------------------
-#define KDF_SK_M        12                  // minimizer length: 24-bit canonical m-mers
-#ifndef KDF_SK_MAXPROBE
-#define KDF_SK_MAXPROBE 64u
-#endif
-//                // slots of a bucket a probe may visit before it turns to the overflow table
-// ORDER of the minimizer scheme: an injective 24-bit scramble (odd multiply mod 2^24, xor-shift) of the canonical
-// m-mer code.  Its top bits name the bucket, so they must be well mixed; one full-rate v_mul_u32_u24.
-// The code is XORed with a constant first: without it the homopolymer AAAAAAAAAAAA (canonical code 0) had order value 0,
-// the global minimum, so EVERY k-mer that merely touches a poly-A / poly-T run of 12 bases was sent to one bucket
-// (measured on a repeat-rich 100 Mbp genome: 167 M spills, a 765 ms pass).  With it a low-complexity m-mer wins a
-// window as often as any other, and only the windows that lie INSIDE a repeat (few distinct k-mers) keep it.
-#define KDF_SK_ORDER_XOR 0x5A3C96u
-__host__ __device__ __forceinline__ uint32_t kdf_sk_order(uint32_t cm) {
-    uint32_t g = ((cm ^ KDF_SK_ORDER_XOR) * 0x9E3779u) & 0xFFFFFFu;
-    return g ^ (g >> 11);
-}
-// minimizer order value of a canonical k-mer x (MSB-first code), k >= KDF_SK_M
-__host__ __device__ __forceinline__ uint32_t kdf_sk_min_of_key(uint64_t x, int k) {
-    constexpr uint32_t MM = (1u << (2 * KDF_SK_M)) - 1;
-    const uint64_t y = kdf_rev2(~x) >> (64 - 2 * k);           // reverse complement of x
-    uint32_t g = 0xFFFFFFFFu;
-    for (int j = 0; j <= k - KDF_SK_M; ++j) {
-        const uint32_t fw = (uint32_t)(x >> (2 * (k - KDF_SK_M - j))) & MM;    // m-mer at offset j
-        const uint32_t rc = (uint32_t)(y >> (2 * j)) & MM;                      // its reverse complement
-        const uint32_t o = kdf_sk_order(fw < rc ? fw : rc);
-        g = o < g ? o : g;
-    }
-    return g;
-}
-// Minimizers are MINIMA of the order: their order values crowd towards 0 (the smallest of 20 uniform values has
-// mean 2^24 / 21), so the bucket cannot be taken from the order value's own top bits.  A second 24-bit bijection
-// (two odd multiplies mod 2^24 around an xor-shift) spreads them; the bucket is the top bits of THAT.
-__host__ __device__ __forceinline__ uint32_t kdf_sk_spread(uint32_t g) {
-    uint32_t h = (g * 0x6A5D39u) & 0xFFFFFFu;
-    h ^= h >> 13;
-    return (h * 0xC2B2AFu) & 0xFFFFFFu;
-}
-// bucket of an order value: the top bits of its spread (nb_bits = log2cap - bucket_bits <= 24)
-__host__ __device__ __forceinline__ uint32_t kdf_sk_bucket_of(uint32_t g, uint32_t nb_bits) {
-    return nb_bits ? (kdf_sk_spread(g) >> (24 - nb_bits)) : 0u;
-}
-// slot of a key inside its bucket (SK layout): two 32-bit multiplies; only the top bucket_bits bits are used
-__host__ __device__ __forceinline__ uint32_t kdf_sk_slot(uint64_t key, uint32_t bucket_bits) {
-    uint32_t h = (uint32_t)key * 0x9E3779B1u ^ (uint32_t)(key >> 32) * 0x85EBCA77u;
-    h ^= h >> 15;
-    return (h * 0x2C1B3C6Du) >> (32 - bucket_bits);
-}
-// bucket of an order value in table t
-__device__ __forceinline__ uint32_t kdf_sk_bucket(const KdfTable &t, uint32_t g) {
-    const uint32_t nb_bits = t.log2cap - t.bucket_bits;
-    if (!t.sk_assign) return kdf_sk_bucket_of(g, nb_bits);
-    const uint32_t h = kdf_sk_spread(g);
-    return ((t.sk_c1 ? (h >> (24 - t.sk_c1)) : 0u) << t.sk_c2) | t.sk_assign[h];
-}
-// first slot of key's probe sequence in an SK table
-__device__ __forceinline__ uint64_t kdf_sk_home(const KdfTable &t, uint64_t key) {
-    const uint64_t b = kdf_sk_bucket(t, kdf_sk_min_of_key(key, (int)t.k));
-    return (b << t.bucket_bits) | kdf_sk_slot(key, t.bucket_bits);
-}
-
 __device__ __forceinline__ void kdf_sat_add(uint32_t *p, uint32_t add) {
     // saturating uint32 add (Jellyfish's output counter is 4 bytes): a wrapping
     // add is always followed by this thread's atomicMax, so the last operation
@@ -168,6 +116,7 @@ __device__ __forceinline__ void kdf_sat_add(uint32_t *p, uint32_t add) {
 }
 
 // ---- narrow keys (k <= 32) -------------------------------------------------
+// (`key` / `klo` below are STORED FORMS h: what the table's lo[] words are compared with)
 
 // returns false when the bucket is full (caller raises the error flag)
 template <bool INSERT>
@@ -189,72 +138,10 @@ __device__ __forceinline__ bool kdf_add_narrow(const KdfTable &t, uint64_t key, 
     }
 }
 
-// SK layout, one key through global memory (index loads, merges, rehash).  kdf_sk_main_add tries the key's bucket
-// neighbourhood and returns false when it holds neither the key nor an empty slot: the key then belongs to the
-// overflow table (kdf_sk_ovf_add; false there = the overflow table is full, the host sizes it so that cannot happen).
-template <bool INSERT>
-__device__ __forceinline__ bool kdf_sk_main_add(const KdfTable &t, uint64_t key, uint32_t add, uint32_t &claimed) {
-    const uint64_t bmask = (1ull << t.bucket_bits) - 1;
-    uint64_t slot = kdf_sk_home(t, key);
-    const uint64_t base = slot & ~bmask;
-    const uint64_t lim = bmask + 1 < KDF_SK_MAXPROBE ? bmask + 1 : KDF_SK_MAXPROBE;
-    for (uint64_t i = 0; i < lim; ++i) {
-        uint64_t cur = t.lo[slot];
-        if (cur == KDF_EMPTY) {
-            if (!INSERT) return true;
-            cur = atomicCAS((unsigned long long *)&t.lo[slot], KDF_EMPTY, key);
-            if (cur == KDF_EMPTY) { claimed++; cur = key; }
-        }
-        if (cur == key) { if (add) kdf_sat_add(&t.cnt[slot], add); return true; }
-        slot = base | ((slot + 1) & bmask);
-    }
-    return false;
-}
-template <bool INSERT>
-__device__ __forceinline__ bool kdf_sk_ovf_add(const KdfTable &t, uint64_t key, uint32_t add, uint32_t &claimed) {
-    if (!t.ovf_lo) return false;
-    const uint64_t omask = (1ull << t.ovf_log2cap) - 1;
-    uint64_t os = kdf_mix64(key) >> (64 - t.ovf_log2cap);
-    for (uint64_t i = 0; i <= omask; ++i) {
-        uint64_t cur = t.ovf_lo[os];
-        if (cur == KDF_EMPTY) {
-            if (!INSERT) return true;
-            cur = atomicCAS((unsigned long long *)&t.ovf_lo[os], KDF_EMPTY, key);
-            if (cur == KDF_EMPTY) { claimed++; cur = key; }
-        }
-        if (cur == key) { if (add) kdf_sat_add(&t.ovf_cnt[os], add); return true; }
-        os = (os + 1) & omask;
-    }
-    return false;
-}
-// count of key in an SK table (0 when absent)
-__device__ __forceinline__ uint32_t kdf_count_sk(const KdfTable &t, uint64_t key) {
-    const uint64_t bmask = (1ull << t.bucket_bits) - 1;
-    uint64_t slot = kdf_sk_home(t, key);
-    const uint64_t base = slot & ~bmask;
-    const uint64_t lim = bmask + 1 < KDF_SK_MAXPROBE ? bmask + 1 : KDF_SK_MAXPROBE;
-    for (uint64_t i = 0; i < lim; ++i) {
-        const uint64_t cur = t.lo[slot];
-        if (cur == key) return t.cnt[slot];
-        if (cur == KDF_EMPTY) return 0u;
-        slot = base | ((slot + 1) & bmask);
-    }
-    if (!t.ovf_lo) return 0u;
-    const uint64_t omask = (1ull << t.ovf_log2cap) - 1;
-    uint64_t os = kdf_mix64(key) >> (64 - t.ovf_log2cap);
-    for (uint64_t i = 0; i <= omask; ++i) {
-        const uint64_t cur = t.ovf_lo[os];
-        if (cur == key) return t.ovf_cnt[os];
-        if (cur == KDF_EMPTY) return 0u;
-        os = (os + 1) & omask;
-    }
-    return 0u;
-}
-
-// returns the slot of key or ~0 when absent
+// returns the slot of the key with stored form `key` or ~0 when absent
 __device__ __forceinline__ uint64_t kdf_find_narrow(const KdfTable &t, uint64_t key) {
     const uint64_t bmask = (1ull << t.bucket_bits) - 1;
-    uint64_t slot = kdf_home(t, kdf_hash(key, 0));
+    uint64_t slot = kdf_home(t, key);
     const uint64_t base = slot & ~bmask;
     for (uint64_t i = 0; i <= bmask; ++i) {
         uint64_t cur = t.lo[slot];
@@ -334,7 +221,7 @@ __device__ __forceinline__ bool kdf_add_wide(const KdfTable &t, bool todo, uint6
 
 __device__ __forceinline__ uint64_t kdf_find_wide(const KdfTable &t, uint64_t klo, uint64_t khi) {
     const uint64_t bmask = (1ull << t.bucket_bits) - 1;
-    uint64_t slot = kdf_home(t, kdf_hash(klo, khi));
+    uint64_t slot = kdf_home(t, klo);
     const uint64_t base = slot & ~bmask;
     for (uint64_t i = 0; i <= bmask; ++i) {
         uint64_t chi = t.hi[slot];

@@ -13,7 +13,6 @@
 #include "kdf.h"
 #include "kdf_device.h"
 #include "kdf_binned.h"
-#include "kdf_sk.h"
 #include "kdf_merge.h"
 
 // sorted export lives in kdf_sort.hip (rocPRIM radix sort)
@@ -64,6 +63,7 @@ __global__ __launch_bounds__(256) void kdf_stream_kernel(
                         kdf_window_wide((const uint64_t (&)[4])w, b + u, k, klo[u], khi[u]);
                     }
                     const uint64_t hsh = kdf_hash(klo[u], khi[u]);
+                    klo[u] = hsh;                                  // from here on the key is its stored form (kdf_device.h)
                     slot[u] = kdf_home(t, hsh);
                     if (sliced && ((valid >> (b + u)) & 1) && kdf_slice(hsh, t.key_parts) != t.key_part) { valid &= ~(1ull << (b + u)); --nwin; }
                 }
@@ -78,7 +78,6 @@ __global__ __launch_bounds__(256) void kdf_stream_kernel(
                     const bool ok = (valid >> (b + u)) & 1;
                     if constexpr (MODE == MODE_SCAN) {
                         if (!ok) continue;
-                        if (KW == 1 && t.sk) { if (kdf_count_sk(t, klo[u]) != 0) hits |= 1ull << (b + u); continue; }
                         uint64_t s = KW == 1 ? kdf_find_narrow(t, klo[u]) : kdf_find_wide(t, klo[u], khi[u]);
                         if (s != ~0ull && t.cnt[s] != 0) hits |= 1ull << (b + u);
                     } else if constexpr (KW == 1) {
@@ -105,11 +104,12 @@ __global__ __launch_bounds__(256) void kdf_stream_kernel(
     }
 }
 
-// thread per key: insert with an explicit add (filter load: add = 0; rehash: add = count)
+// thread per key: insert with an explicit add (filter load: add = 0; rehash: add = count).
+// stored != 0: klo[] already holds stored forms (the slots of a table that is being rehashed), else keys.
 template <int KW>
 __global__ __launch_bounds__(256) void kdf_insert_keys_kernel(
     const uint64_t *__restrict__ klo, const uint64_t *__restrict__ khi,
-    const uint32_t *__restrict__ add, uint64_t n, KdfTable t, KdfCtl *ctl, int skip_empty)
+    const uint32_t *__restrict__ add, uint64_t n, KdfTable t, KdfCtl *ctl, int skip_empty, int stored)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t claimed = 0;
@@ -119,11 +119,12 @@ __global__ __launch_bounds__(256) void kdf_insert_keys_kernel(
         const bool present = KW == 1 ? (lo != KDF_EMPTY) : (hi != KDF_EMPTY);
         const bool todo = i < n && (present || !skip_empty);
         const uint32_t a = (todo && add) ? add[i] : 0u;
-        const uint64_t slot = kdf_home(t, kdf_hash(lo, hi));
+        const uint64_t h = stored ? lo : kdf_hash(lo, (KW == 2 ? hi & ~KDF_PENDING : 0));
+        const uint64_t slot = kdf_home(t, h);
         if constexpr (KW == 1) {
-            if (todo && !kdf_add_narrow<true>(t, lo, a, slot, t.lo[slot], claimed)) full = true;
+            if (todo && !kdf_add_narrow<true>(t, h, a, slot, t.lo[slot], claimed)) full = true;
         } else {
-            if (!kdf_add_wide<true>(t, todo, lo, hi & ~KDF_PENDING, a, slot, claimed)) full = true;
+            if (!kdf_add_wide<true>(t, todo, h, hi & ~KDF_PENDING, a, slot, claimed)) full = true;
         }
     }
     if (full) atomicOr(&ctl->error, 1u);
@@ -142,8 +143,7 @@ __global__ __launch_bounds__(256) void kdf_query_kernel(
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (KW == 1 && t.sk) { out[i] = kdf_count_sk(t, klo[i]); return; }
-    const uint64_t s = KW == 1 ? kdf_find_narrow(t, klo[i]) : kdf_find_wide(t, klo[i], khi[i]);
+    const uint64_t s = KW == 1 ? kdf_find_narrow(t, kdf_hash(klo[i], 0)) : kdf_find_wide(t, kdf_hash(klo[i], khi[i]), khi[i]);
     out[i] = (s == ~0ull) ? 0u : t.cnt[s];
 }
 
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void kdf_export_kernel(
         if (keep) {
             const uint64_t pos = base + __popcll(b & ((1ull << lane) - 1));
             if (pos < out_cap) {
-                olo[pos] = lo;
+                olo[pos] = kdf_key_lo(lo, hi);                       // the key back from its stored form
                 if (KW == 2 && ohi) ohi[pos] = hi;
                 if (ocnt) ocnt[pos] = c;
             }
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(KDF_EXPORT1_THREADS) void kdf_export1_kernel(KdfTab
     for (int r = 0; r < ROWS; ++r) {
         if ((kb[r] >> lane) & 1) {
             const uint64_t pos = base + __popcll(kb[r] & ((1ull << lane) - 1));
-            if (pos < out_cap) { olo[pos] = lo[r]; if (KW == 2 && ohi) ohi[pos] = hi[r]; if (ocnt) ocnt[pos] = c[r]; }
+            if (pos < out_cap) { olo[pos] = kdf_key_lo(lo[r], KW == 2 ? hi[r] : 0); if (KW == 2 && ohi) ohi[pos] = hi[r]; if (ocnt) ocnt[pos] = c[r]; }
         }
         base += __popcll(kb[r]);
     }
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void kdf_sieve_from_table_kernel(KdfTable t, u
     const uint64_t lo = t.lo[i], hi = KW == 2 ? t.hi[i] : 0;
     if ((KW == 1 ? lo : hi) == KDF_EMPTY) return;
     uint64_t w, b;
-    kdf_sieve_bits(kdf_hash(lo, hi), wmask, w, b);
+    kdf_sieve_bits(lo, wmask, w, b);                                // the slot holds the hash
     atomicOr((unsigned long long *)&words[w], (unsigned long long)b);
 }
 
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(KB_THREADS) void kdf_sieve_count_kernel(
                 if (sl != ~0ull && t.cnt[sl] != 0) { const uint32_t p = wqpos[from + lane]; atomicOr(&hit_bits[p >> 6], 1ull << (p & 63)); }
             }
         } else {
-            const uint64_t slot = kdf_home(t, kdf_hash(klo, khi));
+            const uint64_t slot = kdf_home(t, klo);              // the queue holds stored forms
             if constexpr (KW == 1) { if (todo && !kdf_add_narrow<false>(t, klo, 1u, slot, t.lo[slot], claimed)) full = true; }
             else { if (!kdf_add_wide<false>(t, todo, klo, khi, 1u, slot, claimed)) full = true; }
         }
@@ -379,8 +379,7 @@ __global__ __launch_bounds__(KB_THREADS) void kdf_sieve_count_kernel(
             uint64_t w[HB]; uint32_t hb[HB];
 #pragma unroll
             for (int u = 0; u < HB; ++u) {
-                uint64_t lo, hi; win.key(u0 + u, lo, hi);
-                const uint64_t hsh = kdf_hash(lo, hi);
+                uint64_t hsh, hi; win.stored(u0 + u, hsh, hi);
                 hb[u] = (uint32_t)hsh & 0xFFFu;
                 w[u] = svw[(hsh >> 12) & sv.wmask];
             }
@@ -391,7 +390,7 @@ __global__ __launch_bounds__(KB_THREADS) void kdf_sieve_count_kernel(
                 if (mk) {
                     const uint32_t at = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
                     if (ok) {
-                        uint64_t lo, hi; win.key(u0 + u, lo, hi); wqlo[at] = lo; if constexpr (KW == 2) wqhi[at] = hi;
+                        uint64_t lo, hi; win.stored(u0 + u, lo, hi); wqlo[at] = lo; if constexpr (KW == 2) wqhi[at] = hi;
                         if constexpr (SCAN) wqpos[at] = (uint32_t)(tile * 64 + (threadIdx.x % TPT) * WPT + u0 + u);
                     }
                     wq_n += (uint32_t)__popcll(mk);
@@ -426,6 +425,7 @@ struct kdf_engine {
     int k = 0;
     int kw = 1;
     int n_cu = 256;               // compute units of the device (persistent-kernel grids)
+    uint64_t dev_total_bytes = 0; // HBM of the device (sizes the entry ring's budget)
     KdfTable t{};                 // live table
     uint64_t cap = 0;
     KdfCtl *ctl = nullptr;        // device
@@ -440,69 +440,64 @@ struct kdf_engine {
     // grow-only device staging for the host-buffer entry points
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t stage_bytes[4] = {0, 0, 0, 0};
-    // binned (LDS-bucket) path: scratch + options
-    unsigned long long *kb_small = nullptr;   // hist1 | bin_start | cursor | chunk_first | totals
-    unsigned long long *kb_totals_host = nullptr;   // pinned [4]
-    void *kb_buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ent_lo, ent_hi, chunk_off, failed, hist_wg, wg_base
+    // ---- binned (LDS-bucket) path: scratch + options -------------------------------------------------------------------
+    unsigned long long *kb_small = nullptr;   // hist1 | totals[16] | failed_flag
+    unsigned long long *kb_totals_host = nullptr;   // pinned [16 + KB_MAX_PASS]
+    void *kb_buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ring (entries), -, chunk_off, failed, hist_wg, wg_base
     size_t kb_bytes[6] = {0, 0, 0, 0, 0, 0};
+    KbPass *kb_pass = nullptr;                       // [KB_MAX_PASS] descriptors of the pending passes (device)
+    // The entry ring: A0/A1/B append a partitioned pass per call; kernel C applies all pending passes at once when the
+    // table is needed or the ring is full (kb_flush).  Reserved by upper bounds (one entry per stream position), so no
+    // host round trip sits between the stages.
+    uint64_t ring_entries = 0, ring_rows = 0;        // capacity: entries (8 B x kw each), rows of chunk_off
+    uint64_t ring_used = 0, rows_used = 0;           // reserved by the pending passes
+    uint32_t n_pass = 0;
+    uint64_t pend_positions = 0;                     // stream positions of the pending passes (upper bound of their entries)
+    KbPlan pend_plan{};                              // geometry (c1, c2, key slice) the pending passes were partitioned with
+    bool pend_filtered = false;                      // the pending passes are count --if passes
+    uint64_t stat_flushes = 0;
+    double grow_ratio = 0.0;                         // new distinct keys per counted window at the last flush (0: unknown)
+    // L1: small insert batches are concatenated (packed) in a pending stream first; the partition runs over ~2^30 positions
+    uint64_t *l1_packed = nullptr, *l1_mask = nullptr;
+    uint64_t l1_cap_tiles = 0, l1_tiles = 0;
     uint32_t opt_key_parts = 0, opt_key_part = 0;    // count only one slice of the key space (KdfTable::key_parts)
-    uint64_t opt_binned_min_positions = 1ull << 22;  // smaller batches use the direct global-table kernels
-    uint64_t opt_binned_bytes_per_position = 70;     // insert passes go binned only from table_bytes / 70 positions on (use_binned)
-    uint64_t opt_binned_max_positions = 1ull << 31;  // longer streams are walked in several binned passes: a pass must add
-                                                     // < 2^32 to any slot (kernel C saturates by comparing with the HBM count)
+    uint64_t opt_binned_min_positions = 1ull << 22;  // fewer pending positions at flush time use the direct global-table kernels
+    uint64_t opt_binned_bytes_per_position = 70;     // ... and so does a flush of fewer than table_bytes / 70 positions (use_binned)
+    uint64_t opt_binned_max_positions = 1ull << 31;  // longer streams are partitioned in several passes
     uint32_t opt_binned_filtered_min_log2cap = 23;   // count --if goes binned from 2^23 slots (measured crossover)
     uint64_t opt_merge_min_pairs = KDF_MERGE_MIN_PAIRS;   // below this many pairs a merge goes straight to the atomic insert (tests lower it)
     uint32_t opt_hash_shift = 0;                     // KdfTable::hshift of the tables this engine creates (owner tables)
-    int opt_force_path = 0;                          // 0 auto, 1 direct, 2 binned, 3 super-k-mer (kdf_sk.h)
-    uint32_t opt_sk_min_k = 20;                      // auto (option sk_auto): narrow keys from this k on take the super-k-mer path
-    int opt_binned_cells = 0;                        // binned path, opt-in (2): no histogram pass, fixed (bin, workgroup) cells; falls back to A0 + A1 when
-                                                     // a cell overflows.  Measured at 10 M reads: k = 63 26.5 -> 24.3 ms, k = 31 14.3 -> 14.6 ms, and only
-                                                     // when the batch fills the cells to 50-80 %: not a default
-    bool cells_overflowed = false;                   // sticky: this engine's input is too skewed for fixed cells
-    int opt_binned_pool = 0;                         // binned path: 1 = pool scatter without the histogram pass (measured SLOWER: 6.4 ms
-                                                     // against A0 + A1 = 5.9 ms, the scatter sits at the 128-VGPR limit), 0 = A0 + A1 + B
+    int opt_force_path = 0;                          // 0 auto, 1 direct, 2 binned, 4 sieve only (count --if)
+    int opt_defer = 1;                               // 1: kernel C is deferred over the pending passes; 0: every count call ends with a flush
+    uint64_t opt_defer_max_bytes = 0;                // budget of the entry ring (0: 40 % of the device's memory)
+    uint64_t opt_l1_positions = 1ull << 30;          // pending-stream size from which it is partitioned
+    uint64_t opt_l1_direct_positions = 1ull << 28;   // batches from this size on are partitioned where they lie (no copy)
     // double-buffered feeding (kdf_upload_reads_async / kdf_count_uploaded): two device staging slots filled on a copy
     // stream of their own, so the H2D copy of batch i + 1 runs under the count of batch i
     void *up_buf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; size_t up_bytes[2][2] = {{0, 0}, {0, 0}};
     uint64_t up_n[2] = {0, 0}; bool up_valid[2] = {false, false};
     hipStream_t copy_stream = nullptr; hipEvent_t up_done[2] = {nullptr, nullptr}, use_done[2] = {nullptr, nullptr};
     uint64_t stat_heavy_buckets = 0;
-    bool kb_skewed = false;                          // the last binned pass saw a skewed coarse histogram (kdf_binned.h kb_count_hits)
-    void *kb_heavy = nullptr;                        // heavy buckets of skewed binned passes (kdf_binned.h kb_heavy_slice_kernel)
+    void *kb_heavy = nullptr;                        // heavy buckets of skewed flushes (kdf_binned.h kb_heavy_slice_kernel)
     void *merge_buf = nullptr; size_t merge_bytes = 0;   // kdf_merge.h: block counts / offsets of the ordered dump, bucket ranges of a merge
     uint32_t merge_flag_host = 0;
     int last_merge_path = 0;                         // 0 none yet, 1 LDS bucket merge launched, 2 plain atomic insert
-    void *kp_buf[8] = {nullptr};                     // pool variant: pool, chunk_bin, chunk_pos, chunk_fill, chunk_list, small, pool_ctr
-    size_t kp_bytes[8] = {0};
     int opt_sieve_bits = 0;                          // sieve bits per filter key (0: 32 up to 2^20 keys, 16 beyond)
-    int opt_sk_auto = 0;                             // 0: the super-k-mer path only when forced (it is at parity with the binned path)
-    // super-k-mer path (kdf_sk.h): scratch, device counters + pinned mirror, overflow table bookkeeping
-    void *sk_buf[16] = {nullptr};
-    size_t sk_bytes[16] = {0};
-    uint32_t *sk_ctrs = nullptr, *sk_ctrs_host = nullptr;
-    uint64_t ovf_used_ub = 0;                        // upper bound of the keys in the overflow table
-    bool ovf_dirty = false;                          // overflow arrays hold entries of an earlier table generation
-    bool sk_attrs_set[64] = {false};
-    uint16_t *sk_assign = nullptr;                   // balanced minimizer -> bucket table (2^24 entries) of geometry (c1, c2) ...
-    uint32_t *sk_weights = nullptr;                  // ... and the weights it was dealt from
-    uint32_t sk_assign_c1 = 0, sk_assign_c2 = 0;     // 0 / 0: no table yet
-    int opt_sk_balance = 1;
-    uint64_t stat_sk_passes = 0, stat_sk_spills = 0, stat_sk_failed = 0, stat_sk_fallbacks = 0;
-    int last_path = 0;                               // count path of the last count call: 0 direct, 1 binned, 2 super-k-mer, 3 sieve
+    bool attrs_set[4] = {false, false, false, false};   // hipFuncSetAttribute done (per key width)
+    int last_path = 0;                               // count path of the last count call: 0 direct, 1 binned, 3 sieve
     uint64_t *sieve = nullptr;                       // blocked Bloom filter over the filter keys (count --if)
     uint64_t sieve_words = 0, sieve_alloc = 0;
     bool sieve_valid = false;
     uint32_t opt_debug_flags = 0;                    // experiments only (KbPlan::dbg)
     uint64_t stat_binned_passes = 0, stat_replayed_buckets = 0;
-    uint64_t stat_dbg[6] = {0, 0, 0, 0, 0, 0};        // diagnostic stamps of the last binned pass
     // optional HIP-event timing of the dominant (stream) kernel
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;   // pending start/stop pairs
     std::vector<uint64_t> prof_tiles;
     double prof_ms = 0.0;
     uint64_t prof_launches = 0, prof_positions = 0;
-    // binned pass: events around each stage (A0 hist, A1 scatter, B finesort, C bucket)
-    std::vector<std::vector<hipEvent_t>> prof_stage_ev;
+    // binned path: events around each stage (A0 hist, A1 scatter, B finesort | C bucket)
+    std::vector<std::vector<hipEvent_t>> prof_stage_ev;   // 4 events: a partition (A0, A1, B); 2 events: a flush (C)
     double prof_stage_ms[4] = {0, 0, 0, 0};
     uint64_t prof_stage_passes = 0;
     std::string err;
@@ -565,8 +560,6 @@ static void table_free(KdfTable &t) {
     if (t.lo) (void)hipFree(t.lo);
     if (t.hi) (void)hipFree(t.hi);
     if (t.cnt) (void)hipFree(t.cnt);
-    if (t.ovf_lo) (void)hipFree(t.ovf_lo);
-    if (t.ovf_cnt) (void)hipFree(t.ovf_cnt);
     t = KdfTable{};
 }
 
@@ -616,11 +609,10 @@ static int ctl_reset(kdf_engine *h, bool keep_windows) {
 template <typename F>
 static int by_width(kdf_engine *h, F &&f) { return h->kw == 1 ? f(std::integral_constant<int, 1>{}) : f(std::integral_constant<int, 2>{}); }
 
-static int sk_table_rehash(kdf_engine *h, uint32_t new_log2);
-
 // rehash the live table into one with 2^new_log2 slots
 static int table_rehash(kdf_engine *h, uint32_t new_log2) {
-    if (h->t.sk) return sk_table_rehash(h, new_log2);
+    // (the window counter lives on the device between synchronisations: pending partition passes have added to it)
+    { int rc0 = ctl_sync(h, nullptr); if (rc0) return rc0; }
     { int rc0 = materialize(h); if (rc0) return rc0; }
     KdfTable nt;
     int rc = table_alloc(h, new_log2, nt);
@@ -632,10 +624,10 @@ static int table_rehash(kdf_engine *h, uint32_t new_log2) {
     const unsigned blocks = (unsigned)((old_cap + 255) / 256);
     if (h->kw == 1)
         hipLaunchKernelGGL(kdf_insert_keys_kernel<1>, dim3(blocks), dim3(256), 0, h->stream,
-                           (const uint64_t *)h->t.lo, (const uint64_t *)nullptr, (const uint32_t *)h->t.cnt, old_cap, nt, h->ctl, 1);
+                           (const uint64_t *)h->t.lo, (const uint64_t *)nullptr, (const uint32_t *)h->t.cnt, old_cap, nt, h->ctl, 1, 1);
     else
         hipLaunchKernelGGL(kdf_insert_keys_kernel<2>, dim3(blocks), dim3(256), 0, h->stream,
-                           (const uint64_t *)h->t.lo, (const uint64_t *)h->t.hi, (const uint32_t *)h->t.cnt, old_cap, nt, h->ctl, 1);
+                           (const uint64_t *)h->t.lo, (const uint64_t *)h->t.hi, (const uint32_t *)h->t.cnt, old_cap, nt, h->ctl, 1, 1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { table_free(nt); return fail(h, KDF_ERR_HIP, "rehash launch failed: %s", hipGetErrorString(e)); }
     bool full = false;
@@ -681,17 +673,22 @@ static void prof_collect(kdf_engine *h) {
         float ms = 0.f;
         (void)hipEventSynchronize(h->prof_ev[i].second);
         if (hipEventElapsedTime(&ms, h->prof_ev[i].first, h->prof_ev[i].second) == hipSuccess) {
-            h->prof_ms += ms; h->prof_launches++; h->prof_positions += h->prof_tiles[i] * KDF_TILE;
+            h->prof_ms += ms; h->prof_positions += h->prof_tiles[i] * KDF_TILE;
+            if (h->prof_tiles[i]) h->prof_launches++;                // (a flush has no positions of its own: its time belongs to the passes it applies)
         }
         (void)hipEventDestroy(h->prof_ev[i].first); (void)hipEventDestroy(h->prof_ev[i].second);
     }
     h->prof_ev.clear(); h->prof_tiles.clear();
     for (auto &ev : h->prof_stage_ev) {
-        if (ev.size() == 5) {
-            (void)hipEventSynchronize(ev[4]);
-            bool ok = true; float ms[4];
-            for (int i = 0; i < 4; ++i) ok = ok && hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]) == hipSuccess;
-            if (ok) { for (int i = 0; i < 4; ++i) h->prof_stage_ms[i] += ms[i]; h->prof_stage_passes++; }
+        if (ev.size() == 4) {                                     // a partition pass: A0, A1, B
+            (void)hipEventSynchronize(ev[3]);
+            bool ok = true; float ms[3];
+            for (int i = 0; i < 3; ++i) ok = ok && hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]) == hipSuccess;
+            if (ok) { for (int i = 0; i < 3; ++i) h->prof_stage_ms[i] += ms[i]; h->prof_stage_passes++; }
+        } else if (ev.size() == 2) {                              // a flush: kernel C over the pending passes
+            (void)hipEventSynchronize(ev[1]);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) h->prof_stage_ms[3] += ms;
         }
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
     }
@@ -699,17 +696,18 @@ static void prof_collect(kdf_engine *h) {
 }
 
 // ---------------------------------------------------------------------------
-// binned path (kdf_binned.h)
+// binned path (kdf_binned.h): partition passes into the entry ring, deferred kernel C
 
-static int kb_reserve(kdf_engine *h, int i, size_t bytes) {
+static int kb_reserve(kdf_engine *h, int i, size_t bytes, bool exact = false) {
     if (h->kb_bytes[i] >= bytes) return KDF_OK;
     if (h->kb_buf[i]) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->kb_buf[i]); h->kb_buf[i] = nullptr; h->kb_bytes[i] = 0; }
-    const size_t want = bytes + bytes / 16 + 4096;
+    const size_t want = exact ? bytes + 4096 : bytes + bytes / 16 + 4096;
     HIPCHK(h, hipMalloc(&h->kb_buf[i], want));
     h->kb_bytes[i] = want;
     return KDF_OK;
 }
 
+// the partition geometry for a table: coarse / fine bits; sub_bits = what the bucket kernel resolves itself
 static KbPlan kb_make_plan(const KdfTable &t) {
     KbPlan p{};
     p.log2cap = t.log2cap; p.bucket_bits = t.bucket_bits;
@@ -726,175 +724,122 @@ static KbPlan kb_make_plan(const KdfTable &t) {
 }
 
 template <int KW>
-static int kb_set_lds_attrs(kdf_engine *h, size_t a1, size_t b, size_t c) {
+static int kb_set_lds_attrs(kdf_engine *h, size_t a1, size_t b, size_t c, size_t hv) {
     HIPCHK(h, hipFuncSetAttribute((const void *)(kb_scatter1_kernel<KW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a1));
     HIPCHK(h, hipFuncSetAttribute((const void *)(kb_scatter1_kernel<KW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a1));
     HIPCHK(h, hipFuncSetAttribute((const void *)kb_finesort_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b));
-    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_INSERT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c));
-    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_FILTERED, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c));
-    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_REPLAY, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c));
 #define KB_SETV(V) \
-    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_INSERT, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(c + KB_C_QEXTRA(V, KW)))); \
-    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_FILTERED, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(c + KB_C_QEXTRA(V, KW))));
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_INSERT, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c)); \
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_FILTERED, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c));
     KB_SETV(1)
     KB_SETV(2)
 #undef KB_SETV
+    if (KW == 1) {
+        HIPCHK(h, hipFuncSetAttribute((const void *)kb_heavy_slice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hv));
+        HIPCHK(h, hipFuncSetAttribute((const void *)kb_heavy_combine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hv));
+    }
     return KDF_OK;
 }
 
 static int table_rehash(kdf_engine *h, uint32_t new_log2);
-template <int KW>
-static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases, bool filtered, bool force_exact = false);
 
-// the binned path over a stream of any length: passes of at most opt_binned_max_positions
-// positions, each starting on a tile boundary (windows that start in a pass may read on
-// into the next tiles: the stream is one buffer)
-static int kb_passes(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases, bool filtered) {
-    const uint64_t step = h->opt_binned_max_positions;
-    for (uint64_t off = 0; off < n_bases; off += step) {
-        const uint64_t len = std::min<uint64_t>(step, n_bases - off);
-        const uint64_t *p = d_packed + off / 32, *m = d_invalid + off / 64;
-        int rc = h->kw == 1 ? kb_pass<1>(h, p, m, len, filtered) : kb_pass<2>(h, p, m, len, filtered);
-        if (rc) return rc;
-        if (!filtered && off + step < n_bases)                 // room for the next pass (as count_insert_dev does after the last)
-            while (h->distinct * 10 > h->cap * 7)
-                if ((rc = table_rehash(h, h->t.log2cap + 1))) return rc;
-    }
-    return KDF_OK;
-}
-
-// one pass of the binned pipeline over a device-resident stream
-template <int KW>
-static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases, bool filtered, bool force_exact) {
-    constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT, CHUNK = KbCfg<KW>::CHUNK, SLAB = KB_THREADS * WPT;
-    const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
-    if (n_tiles == 0) return KDF_OK;
-    const bool was_lazy = h->lazy_empty;
-    KbPlan plan = kb_make_plan(h->t);
-    plan.dbg = h->opt_debug_flags;
-    plan.key_parts = filtered ? 0 : h->t.key_parts; plan.key_part = h->t.key_part;
+// the small device arrays of the binned path, allocated once per engine; fills the pointers of `s` that do not depend
+// on the ring
+static int kb_scratch(kdf_engine *h, KbScratch &s) {
     const int nb1 = 1 << KB_C1_MAX;
     if (!h->kb_small) {
-        HIPCHK(h, hipMalloc((void **)&h->kb_small, (size_t)(4 * (nb1 + 1) + 16) * 8));
-        HIPCHK(h, hipHostMalloc((void **)&h->kb_totals_host, 128));
+        HIPCHK(h, hipMalloc((void **)&h->kb_small, (size_t)(nb1 + 1 + 16 + 2) * 8));
+        HIPCHK(h, hipMemsetAsync(h->kb_small, 0, (size_t)(nb1 + 1 + 16 + 2) * 8, h->stream));
+        HIPCHK(h, hipHostMalloc((void **)&h->kb_totals_host, (16 + 2) * 8));
+        HIPCHK(h, hipMalloc((void **)&h->kb_pass, sizeof(KbPass) * KB_MAX_PASS));
     }
-    if (KW == 1 && !h->kb_heavy) {                             // heavy buckets of skewed passes (kb_heavy_slice_kernel): ~100 MB, once
+    if (h->kw == 1 && !h->kb_heavy) {                             // heavy buckets of skewed flushes (kb_heavy_slice_kernel): ~100 MB, once
         const size_t pairs = (size_t)KB_HV_MAX * KB_HV_SLICES << 12;
         HIPCHK(h, hipMalloc((void **)&h->kb_heavy, pairs * 12 + (4 + 3 * KB_HV_MAX) * 4));
         HIPCHK(h, hipMemsetAsync((char *)h->kb_heavy + pairs * 12, 0, (4 + 3 * KB_HV_MAX) * 4, h->stream));
     }
-    KbScratch s{};
-    s.hist1 = h->kb_small; s.bin_start = s.hist1 + (nb1 + 1);
-    s.chunk_first = s.bin_start + 2 * (nb1 + 1); s.totals = s.chunk_first + (nb1 + 1);
-    s.failed_flag = (unsigned int *)(s.totals + 8);
-    if (KW == 1 && h->kb_heavy) {
+    s = KbScratch{};
+    s.hist1 = h->kb_small; s.totals = s.hist1 + (nb1 + 1);
+    s.failed_flag = (unsigned int *)(s.totals + 16);
+    s.pass = h->kb_pass;
+    if (h->kw == 1 && h->kb_heavy) {
         const size_t pairs = (size_t)KB_HV_MAX * KB_HV_SLICES << 12;
         s.hv_key = (uint64_t *)h->kb_heavy; s.hv_cnt = (uint32_t *)(s.hv_key + pairs);
         s.hv_ctr = s.hv_cnt + pairs; s.hv_bucket = s.hv_ctr + 4; s.hv_n = s.hv_bucket + KB_HV_MAX; s.hv_failed = s.hv_n + KB_HV_MAX;
     }
+    s.ent = (uint64_t *)h->kb_buf[0];
+    s.chunk_off = (uint32_t *)h->kb_buf[2]; s.failed = (uint32_t *)h->kb_buf[3];
+    s.hist_wg = (uint32_t *)h->kb_buf[4]; s.wg_base = (uint32_t *)h->kb_buf[5];
+    return KDF_OK;
+}
+
+// the ring is empty again: nothing pending, the flush-wide counters zeroed
+static int kb_ring_reset(kdf_engine *h) {
+    h->n_pass = 0; h->ring_used = 0; h->rows_used = 0; h->pend_positions = 0;
+    if (h->kb_small) HIPCHK(h, hipMemsetAsync(h->kb_small + ((1 << KB_C1_MAX) + 1), 0, (16 + 2) * 8, h->stream));   // totals + failed_flag
+    return KDF_OK;
+}
+
+static uint64_t kb_chunk_entries(const kdf_engine *h) { return h->kw == 1 ? KbCfg<1>::CHUNK : KbCfg<2>::CHUNK; }
+// rows of chunk_off a ring of `entries` entries needs, whatever the passes are
+static uint64_t kb_rows_for(const kdf_engine *h, uint64_t entries) { return entries / kb_chunk_entries(h) + (uint64_t)KB_MAX_PASS * ((1 << KB_C1_MAX) + 1) + 1; }
+
+static int kb_flush_ring(kdf_engine *h);
+
+// Room for a pass of need_e entries (upper bound: its stream positions).  A full ring is applied to the table first; a
+// ring that was too small for the pending passes plus this one grows (doubling, up to the budget) while it is empty.
+static int kb_ring_make_room(kdf_engine *h, uint64_t need_e, uint32_t off_stride) {
+    int rc;
+    const uint64_t need_r = need_e / kb_chunk_entries(h) + ((1 << KB_C1_MAX) + 1);
+    bool forced = false;
+    if (h->n_pass >= KB_MAX_PASS || h->ring_used + need_e > h->ring_entries || h->rows_used + need_r > h->ring_rows) {
+        forced = h->n_pass > 0;
+        if (h->n_pass && (rc = kb_flush_ring(h))) return rc;
+    }
+    const uint64_t esz = 8ull * h->kw;
+    const uint64_t budget = h->opt_defer_max_bytes ? h->opt_defer_max_bytes : h->dev_total_bytes / 5 * 2;
+    uint64_t want_e = h->ring_entries;
+    // (at least 128 / 256 MB: small batches never force a flush; with deferral on, room for one more pass like this one)
+    if (need_e > want_e) want_e = std::max<uint64_t>(h->opt_defer ? std::max<uint64_t>(need_e, std::min<uint64_t>(2 * need_e, budget / esz)) : need_e, 1ull << 24);
+    if (forced && h->opt_defer && h->ring_entries * esz < budget)
+        want_e = std::max<uint64_t>(want_e, std::min<uint64_t>(2 * h->ring_entries, std::max<uint64_t>(budget / esz, need_e)));
+    // (rows are sized for the widest offset table, so a table that grows does not move the ring)
+    const uint64_t want_r = kb_rows_for(h, want_e);
+    if (want_e > h->ring_entries || want_r * ((1u << KB_F_BITS_MAX) + 1) * 4 > h->kb_bytes[2]) {
+        if ((rc = kb_reserve(h, 0, want_e * esz, true))) return rc;
+        if ((rc = kb_reserve(h, 2, want_r * ((1u << KB_F_BITS_MAX) + 1) * 4, true))) return rc;
+        h->ring_entries = want_e; h->ring_rows = want_r;
+    }
+    (void)off_stride;
+    return KDF_OK;
+}
+
+// ONE partition pass (A0, A1, B) of a device-resident stream of at most opt_binned_max_positions positions into the ring
+template <int KW>
+static int kb_partition(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases, bool filtered) {
+    constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT, CHUNK = KbCfg<KW>::CHUNK, SLAB = KB_THREADS * WPT;
+    const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
+    if (n_tiles == 0) return KDF_OK;
+    int rc;
+    // pending passes must share their geometry, key slice and mode (kdf_set_option / a mode change flush first)
+    if (h->n_pass && h->pend_filtered != filtered && (rc = kb_flush_ring(h))) return rc;
+    const uint64_t n_entries_max = n_tiles * KDF_TILE;
+    if ((rc = kb_ring_make_room(h, n_entries_max, 0))) return rc;
+    if (h->n_pass == 0) {
+        h->pend_plan = kb_make_plan(h->t);
+        h->pend_plan.key_parts = filtered ? 0 : h->t.key_parts; h->pend_plan.key_part = h->t.key_part;
+        h->pend_filtered = filtered;
+    }
+    KbPlan plan = h->pend_plan;
+    plan.dbg = h->opt_debug_flags;
+    const int nb1 = 1 << KB_C1_MAX, nbins = 1 << plan.c1;
     const size_t lds_b = (size_t)CHUNK * 8 * KW + (size_t)(2 * KB_F + 32) * 4 + 16;
-    const size_t lds_c = ((size_t)8 * KW + 4) * ((size_t)1 << plan.bucket_bits) + (2 + 32 + KB_C_RUNS) * 4 + (size_t)KB_C_RUNS * 8
-                         + (KW == 2 ? (size_t)KB_C_RUNS * 4 : 0);                           // wide: run_hi
     const size_t lds_a1 = (size_t)(SLAB + 2) * 8 * KW + (size_t)nb1 * 16 + (size_t)(2 * (nb1 + 32) + 32) * 4;
-    int rc = KDF_OK;
-    if (!h->sk_attrs_set[2 + KW]) {                           // once per engine (ten hipFuncSetAttribute calls)
-        if ((rc = kb_set_lds_attrs<KW>(h, lds_a1, lds_b, lds_c))) return rc;
-        h->sk_attrs_set[2 + KW] = true;
+    if (!h->attrs_set[KW]) {                                   // once per engine
+        const size_t lds_c = KB_C_LDS(KW, (KW == 1 ? 12 : 11));
+        if ((rc = kb_set_lds_attrs<KW>(h, lds_a1, lds_b, lds_c, ((size_t)12 << 12) + KB_RI_LDS_BYTES))) return rc;
+        h->attrs_set[KW] = true;
     }
-
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    std::vector<hipEvent_t> sev;
-    auto stamp = [&]() { if (h->prof) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, h->stream); sev.push_back(e); } };
-    if (h->prof) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, h->stream); }
-    stamp();                                                   // start of A0 (pool variant: of the scatter)
-
-    const uint64_t nb_table = 1ull << (plan.c1 + plan.c2 + plan.sub_bits);
-    const size_t failed_bytes = (size_t)((nb_table + 31) / 32) * 4;
-    const int nbins = 1 << plan.c1;
-    bool cells = h->opt_binned_cells > 1 && !h->opt_binned_pool && !force_exact && !h->cells_overflowed;
-    {   // ... and only when a cell is expected to stay below 90 % even if every position were a window (few bins = a small table)
-        const uint64_t ns = (n_tiles + (KB_THREADS / TPT) - 1) / (KB_THREADS / TPT);
-        const uint64_t wgs = std::min<uint64_t>((ns + 3) / 4, (uint64_t)h->n_cu);
-        if (n_tiles * KDF_TILE > wgs * (uint64_t)(1 << plan.c1) * (uint64_t)(CHUNK * 9 / 10)) cells = false;
-    }
-    plan.cells = cells ? 1u : 0u;
-    if (cells) {
-        // ---- no histogram pass: every (bin, workgroup) owns a cell of CHUNK entries; A1 fills the cells, B sorts each
-        // cell in place, kernel C reads them as the chunks of the bins
-        const uint64_t n_slabs = (n_tiles + (KB_THREADS / TPT) - 1) / (KB_THREADS / TPT);
-        const uint32_t slabs_per_wg = 4;                                                    // slabs per claimed batch
-        const unsigned grid_a = (unsigned)std::min<uint64_t>((n_slabs + slabs_per_wg - 1) / slabs_per_wg, (uint64_t)h->n_cu);   // persistent: one per CU
-        const uint64_t n_cells = (uint64_t)grid_a * nbins;
-        plan.cell_stride = (uint32_t)CHUNK + 528;               // 33 cache lines (narrow) past the 128 KB: consecutive cells start on different channels
-        if ((rc = kb_reserve(h, 0, n_cells * plan.cell_stride * 8 * KW))) return rc;
-        if ((rc = kb_reserve(h, 2, n_cells * (size_t)plan.off_stride * 4))) return rc;
-        if ((rc = kb_reserve(h, 3, failed_bytes))) return rc;
-        if ((rc = kb_reserve(h, 4, n_cells * 4))) return rc;
-        s.ent_lo = (uint64_t *)h->kb_buf[0];
-        s.chunk_off = (uint32_t *)h->kb_buf[2]; s.failed = (uint32_t *)h->kb_buf[3]; s.hist_wg = (uint32_t *)h->kb_buf[4];
-        HIPCHK(h, hipMemsetAsync(s.failed, 0, failed_bytes, h->stream));
-        HIPCHK(h, hipMemsetAsync(s.failed_flag, 0, 4, h->stream));
-        hipLaunchKernelGGL(kb_cellscan_kernel, dim3(1), dim3(KB_THREADS), 0, h->stream, plan, s, plan.cell_stride, (uint32_t)grid_a);
-        const bool sliced = plan.key_parts > 1;
-        if (sliced) hipLaunchKernelGGL((kb_scatter1_kernel<KW, true, true>), dim3(grid_a), dim3(KB_THREADS), lds_a1, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg, h->ctl);
-        else hipLaunchKernelGGL((kb_scatter1_kernel<KW, false, true>), dim3(grid_a), dim3(KB_THREADS), lds_a1, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg, h->ctl);
-        stamp();                                               // end of the scatter
-        stamp();                                               // (no second stage)
-        hipLaunchKernelGGL((kb_finesort_kernel<KW, true>), dim3((unsigned)n_cells), dim3(KB_THREADS), lds_b, h->stream, plan, s);
-        stamp();                                               // end of the fine sort
-    } else if (h->opt_binned_pool) {
-        // ---- one pass over the stream: scatter into pool chunks, chunk lists, fine sort of chunk groups
-        constexpr int PCH = KB_PCH(KW);
-        const uint64_t n_slabs = (n_tiles + (KB_THREADS / TPT) - 1) / (KB_THREADS / TPT);
-        const uint32_t n_wg = (uint32_t)std::min<uint64_t>(n_slabs, (uint64_t)h->n_cu);       // one resident workgroup per CU (LDS)
-        const uint32_t slabs_per_wg = (uint32_t)((n_slabs + n_wg - 1) / n_wg);
-        const unsigned grid_a = (unsigned)((n_slabs + slabs_per_wg - 1) / slabs_per_wg);
-        const uint64_t max_chunks = n_tiles * KDF_TILE / PCH + (uint64_t)grid_a * nbins + 2;      // one entry per position + every open chunk
-        const uint64_t max_groups = max_chunks / KB_GROUP + nbins + 1;
-        if (max_chunks >= (1ull << 32)) return fail(h, KDF_ERR_INVALID, "binned pass: too many positions for one pass");
-        auto kp_reserve = [&](int i, size_t bytes) -> int {
-            if (h->kp_bytes[i] >= bytes) return KDF_OK;
-            if (h->kp_buf[i]) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->kp_buf[i]); h->kp_buf[i] = nullptr; h->kp_bytes[i] = 0; }
-            const size_t want = bytes + bytes / 16 + 4096;
-            HIPCHK(h, hipMalloc(&h->kp_buf[i], want));
-            h->kp_bytes[i] = want;
-            return KDF_OK;
-        };
-        if ((rc = kp_reserve(0, max_chunks * PCH * 8 * KW))) return rc;
-        for (int i = 1; i <= 4; ++i) if ((rc = kp_reserve(i, max_chunks * 4))) return rc;
-        if ((rc = kp_reserve(5, (size_t)(2 * nb1 + 8) * 4))) return rc;
-        if ((rc = kb_reserve(h, 0, max_groups * CHUNK * 8 * KW))) return rc;                       // sorted groups: what kernel C gathers from
-        if ((rc = kb_reserve(h, 2, max_groups * (size_t)plan.off_stride * 4))) return rc;
-        if ((rc = kb_reserve(h, 3, failed_bytes))) return rc;
-        s.pool = (uint64_t *)h->kp_buf[0];
-        s.chunk_bin = (uint32_t *)h->kp_buf[1]; s.chunk_pos = (uint32_t *)h->kp_buf[2];
-        s.chunk_fill = (uint32_t *)h->kp_buf[3]; s.chunk_list = (uint32_t *)h->kp_buf[4];
-        s.bin_nchunks = (uint32_t *)h->kp_buf[5]; s.bin_chunk_start = s.bin_nchunks + nb1; s.pool_ctr = s.bin_chunk_start + nb1 + 1;
-        s.max_chunks = (uint32_t)max_chunks;
-        s.ent_lo = (uint64_t *)h->kb_buf[0];
-        s.chunk_off = (uint32_t *)h->kb_buf[2]; s.failed = (uint32_t *)h->kb_buf[3];
-        HIPCHK(h, hipMemsetAsync(s.bin_nchunks, 0, (size_t)(2 * nb1 + 8) * 4, h->stream));
-        HIPCHK(h, hipMemsetAsync(s.failed, 0, failed_bytes, h->stream));
-        const size_t lds_a2 = (size_t)(SLAB + 2) * 8 * KW + (size_t)(3 * nb1 + 2 * (nb1 + 32)) * 4;
-        const size_t lds_b2 = (size_t)CHUNK * 8 * KW + (size_t)(2 * KB_F + 40 + 2 * KB_GROUP) * 4 + 16;
-        if (!h->sk_attrs_set[4 + KW]) {
-            HIPCHK(h, hipFuncSetAttribute((const void *)(kb_scatter2_kernel<KW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a2));
-            HIPCHK(h, hipFuncSetAttribute((const void *)(kb_scatter2_kernel<KW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a2));
-            HIPCHK(h, hipFuncSetAttribute((const void *)kb_finesort2_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b2));
-            h->sk_attrs_set[4 + KW] = true;
-        }
-        const bool sliced = plan.key_parts > 1;
-        const KbPool kp{s.pool, s.chunk_bin, s.chunk_pos, s.chunk_fill, s.bin_nchunks, s.pool_ctr, s.max_chunks, plan.c1, plan.key_parts, plan.key_part};
-        if (sliced) hipLaunchKernelGGL((kb_scatter2_kernel<KW, true>), dim3(grid_a), dim3(KB_THREADS), lds_a2, h->stream, d_packed, d_invalid, n_tiles, h->k, kp, slabs_per_wg, h->ctl);
-        else hipLaunchKernelGGL((kb_scatter2_kernel<KW, false>), dim3(grid_a), dim3(KB_THREADS), lds_a2, h->stream, d_packed, d_invalid, n_tiles, h->k, kp, slabs_per_wg, h->ctl);
-        stamp();                                               // end of the scatter
-        hipLaunchKernelGGL(kb_poolscan_kernel, dim3(1), dim3(KB_THREADS), 0, h->stream, plan, s, (uint32_t)CHUNK);
-        hipLaunchKernelGGL(kb_chunklist_kernel, dim3((unsigned)((max_chunks + 255) / 256)), dim3(256), 0, h->stream, s);
-        stamp();                                               // end of the chunk lists
-        hipLaunchKernelGGL(kb_finesort2_kernel<KW>, dim3((unsigned)max_groups), dim3(KB_THREADS), lds_b2, h->stream, plan, s);
-        stamp();                                               // end of the fine sort
-    } else {
-
     // persistent A0/A1 workgroups: each owns slabs_per_wg consecutive slabs
     const uint64_t n_slabs = (n_tiles + (KB_THREADS / TPT) - 1) / (KB_THREADS / TPT);
     const uint32_t n_wg = (uint32_t)std::min<uint64_t>(n_slabs, 4096);
@@ -902,541 +847,199 @@ static int kb_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_in
     const unsigned grid_a = (unsigned)((n_slabs + slabs_per_wg - 1) / slabs_per_wg);
     if ((rc = kb_reserve(h, 4, (size_t)grid_a * nbins * 4))) return rc;
     if ((rc = kb_reserve(h, 5, (size_t)grid_a * nbins * 4))) return rc;
-    s.hist_wg = (uint32_t *)h->kb_buf[4]; s.wg_base = (uint32_t *)h->kb_buf[5];
-    const bool sliced = plan.key_parts > 1;
-    if (sliced) hipLaunchKernelGGL((kb_hist1_kernel<KW, true>), dim3(grid_a), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
-    else hipLaunchKernelGGL((kb_hist1_kernel<KW, false>), dim3(grid_a), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
-    hipLaunchKernelGGL(kb_colscan_kernel, dim3(nbins), dim3(256), 0, h->stream, plan, s, (uint32_t)grid_a);
-    hipLaunchKernelGGL(kb_scan1_kernel, dim3(1), dim3(KB_THREADS), 0, h->stream, plan, s, (uint32_t)CHUNK, h->ctl);
-    HIPCHK(h, hipGetLastError());
-    stamp();                                                   // end of A0 (+ scans)
-    // No host round trip here: the entry buffer is sized for one entry per position and B is launched over the
-    // largest number of chunks the bins can have (its workgroups beyond the real count leave at once).
-    const uint64_t n_entries_max = n_tiles * KDF_TILE;
-    const uint64_t n_chunks_max = n_entries_max / CHUNK + (uint64_t)nbins + 1;
-
-    if ((rc = kb_reserve(h, 0, n_entries_max * 8 * KW))) return rc;         // wide: 16-byte (lo, hi) entries
-    if ((rc = kb_reserve(h, 2, n_chunks_max * (size_t)plan.off_stride * 4))) return rc;
-    if ((rc = kb_reserve(h, 3, failed_bytes))) return rc;
-    s.ent_lo = (uint64_t *)h->kb_buf[0];
-    s.chunk_off = (uint32_t *)h->kb_buf[2]; s.failed = (uint32_t *)h->kb_buf[3];
-    HIPCHK(h, hipMemsetAsync(s.failed, 0, failed_bytes, h->stream));
-
-    if (sliced) hipLaunchKernelGGL((kb_scatter1_kernel<KW, true>), dim3(grid_a), dim3(KB_THREADS), lds_a1, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
-    else hipLaunchKernelGGL((kb_scatter1_kernel<KW, false>), dim3(grid_a), dim3(KB_THREADS), lds_a1, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
-    stamp();                                                   // end of A1
-    hipLaunchKernelGGL(kb_finesort_kernel<KW>, dim3((unsigned)n_chunks_max), dim3(KB_THREADS), lds_b, h->stream, plan, s);
-    stamp();                                                   // end of B
-    }
-    if (filtered && (rc = materialize(h))) return rc;
-    // narrow keys: lookahead + wave-queue variant of kernel C (debug flag 8 selects the plain loop, for A/B runs)
-    const bool var1 = !(h->opt_debug_flags & 8);
-    const int nonempty = h->lazy_empty ? 0 : 1;   // 0: kernel C rewrites every bucket (this IS the clear)
-    // VAR 2 = VAR 1 + wave-aggregated count adds + heavy-bucket listing: for the passes that follow a skewed one (kdf_binned.h kb_count_hits)
-    const bool skew_var = (h->kb_skewed || (h->opt_debug_flags & 4096)) && !cells && !h->opt_binned_pool;   // (debug flag 4096 forces it: fuzzing)
-#define KB_LV(M, V) hipLaunchKernelGGL((kb_bucket_kernel<KW, M, V>), dim3((unsigned)nb_table), dim3(KB_C_CT(KW)), lds_c + KB_C_QEXTRA(V, KW), h->stream, plan, s, h->t, h->ctl, nonempty)
-#define KB_LVS(M) do { if (skew_var) KB_LV(M, 2); else KB_LV(M, 1); } while (0)
-    if (filtered)
-        if (var1) KB_LVS(KB_MODE_FILTERED);
-        else hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_FILTERED, 0>), dim3((unsigned)nb_table), dim3(KB_C_CT(KW)), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty);
-    else
-        if (var1) KB_LVS(KB_MODE_INSERT);
-        else hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_INSERT, 0>), dim3((unsigned)nb_table), dim3(KB_C_CT(KW)), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty);
-    if (KW == 1 && !filtered && var1 && skew_var && s.hv_ctr && plan.bucket_bits == 12) {
-        // the buckets the skewed-pass instantiation left aside
-        const size_t lds_h = (size_t)12 << plan.bucket_bits;
-        hipLaunchKernelGGL(kb_heavy_slice_kernel, dim3(KB_HV_SLICES, KB_HV_MAX), dim3(256), lds_h, h->stream, plan, s);
-        hipLaunchKernelGGL(kb_heavy_combine_kernel, dim3(KB_HV_MAX), dim3(256), lds_h, h->stream, plan, s, h->t, h->ctl, nonempty);
-    }
-    HIPCHK(h, hipGetLastError());
-    if (h->prof) {
-        stamp();                                               // end of C
-        (void)hipEventRecord(e1, h->stream);
-        h->prof_ev.emplace_back(e0, e1);
-        h->prof_tiles.push_back(n_tiles);
-        h->prof_stage_ev.push_back(sev);
-    }
-    HIPCHK(h, hipMemcpyAsync(h->kb_totals_host, s.totals, 128, hipMemcpyDeviceToHost, h->stream));
-    bool full = false;
-    if ((rc = ctl_sync(h, &full))) return rc;
-    h->stat_binned_passes++;
-    h->lazy_empty = false;
-    for (int i = 0; i < 6; ++i) h->stat_dbg[i] = h->kb_totals_host[9 + i];
-    h->stat_heavy_buckets += h->kb_totals_host[4];
-    h->kb_skewed = !cells && !h->opt_binned_pool && h->kb_totals_host[7] != 0;      // what the NEXT pass of this engine is launched for
-    if (((unsigned int *)(h->kb_totals_host + 8))[0] && cells) {
-        // a cell overflowed: B and C did nothing (they saw the flag).  The windows A1 counted are taken back and the
-        // pass is redone with the exact layout; this engine stays on it (its input is skewed).
-        h->cells_overflowed = true;
-        h->stat_binned_passes--;
-        h->lazy_empty = was_lazy;
-        return kb_pass<KW>(h, d_packed, d_invalid, n_bases, filtered, true);
-    }
-    if (((unsigned int *)(h->kb_totals_host + 8))[0])
-        return fail(h, KDF_ERR_STATE, "binned count: the read stream changed while it was being counted "
-                                      "(is another stream still writing it? synchronise before the call)");
-    const uint64_t n_failed = h->kb_totals_host[2];
-    if (n_failed == 0) return KDF_OK;
-    if (filtered) return fail(h, KDF_ERR_STATE, "binned count --if: a bucket failed (corrupt table?)");
-    // some buckets overflowed: they are untouched in HBM.  Grow the table so
-    // that even if every entry of the failed buckets were new the load stays
-    // <= 0.5, then replay exactly those buckets through the global-atomic path.
-    h->stat_replayed_buckets += n_failed;
-    const uint64_t n_entries = cells ? h->kb_totals_host[5] : h->kb_totals_host[0];     // (cells: the windows the scatter counted)
-    const uint64_t worst = h->distinct + std::min<uint64_t>(n_entries, n_failed * ((n_entries / std::max<uint64_t>(nb_table, 1)) * 4 + 4096));
-    uint32_t want = std::max<uint32_t>(h->t.log2cap + 1, cap_log2_for(worst));
-    if ((rc = table_rehash(h, want))) return rc;
-    hipLaunchKernelGGL((kb_bucket_kernel<KW, KB_MODE_REPLAY, 0>), dim3((unsigned)nb_table), dim3(KB_C_CT(KW)), lds_c, h->stream, plan, s, h->t, h->ctl, 1);
-    HIPCHK(h, hipGetLastError());
-    if ((rc = ctl_sync(h, &full))) return rc;
-    if (full) return fail(h, KDF_ERR_TABLE_FULL, "binned count: bucket overflow during replay (capacity 2^%u)", h->t.log2cap);
-    return KDF_OK;
-}
-
-
-// ---------------------------------------------------------------------------
-// super-k-mer path (kdf_sk.h)
-
-enum { SKB_CHUNKS = 0, SKB_CBIN, SKB_CPOS, SKB_CFILL, SKB_CLIST, SKB_SMALL, SKB_SORTED, SKB_GOFF, SKB_FAILED, SKB_SPKEY, SKB_SPCNT };
-#define SK_RC_EXHAUSTED (-1000)
-
-static int sk_reserve(kdf_engine *h, int i, size_t bytes) {
-    if (h->sk_bytes[i] >= bytes) return KDF_OK;
-    if (h->sk_buf[i]) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->sk_buf[i]); h->sk_buf[i] = nullptr; h->sk_bytes[i] = 0; }
-    const size_t want = bytes + bytes / 16 + 4096;
-    HIPCHK(h, hipMalloc(&h->sk_buf[i], want));
-    h->sk_bytes[i] = want;
-    return KDF_OK;
-}
-
-static int sk_ctrs_init(kdf_engine *h) {
-    if (h->sk_ctrs) return KDF_OK;
-    HIPCHK(h, hipMalloc((void **)&h->sk_ctrs, SKC_N * 4));
-    HIPCHK(h, hipHostMalloc((void **)&h->sk_ctrs_host, SKC_N * 4));
-    return KDF_OK;
-}
-
-// (re)allocate an EMPTY overflow table of 2^log2cap slots for table t
-static int ovf_alloc(kdf_engine *h, KdfTable &t, uint32_t log2cap) {
-    if (t.ovf_lo && t.ovf_log2cap != log2cap) {
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        (void)hipFree(t.ovf_lo); (void)hipFree(t.ovf_cnt); t.ovf_lo = nullptr; t.ovf_cnt = nullptr;
-    }
-    const uint64_t cap = 1ull << log2cap;
-    if (!t.ovf_lo) {
-        HIPCHK(h, hipMalloc((void **)&t.ovf_lo, cap * 8));
-        HIPCHK(h, hipMalloc((void **)&t.ovf_cnt, cap * 4));
-        t.ovf_log2cap = log2cap;
-    }
-    HIPCHK(h, hipMemsetAsync(t.ovf_lo, 0xFF, cap * 8, h->stream));
-    HIPCHK(h, hipMemsetAsync(t.ovf_cnt, 0, cap * 4, h->stream));
-    return KDF_OK;
-}
-
-// make room for `more` further keys in the live overflow table (load <= 0.5), re-placing what it holds
-static int ovf_ensure(kdf_engine *h, uint64_t more) {
-    const uint64_t need = (h->ovf_used_ub + more) * 2;
-    if (h->t.ovf_lo && need <= (1ull << h->t.ovf_log2cap)) return KDF_OK;
-    const uint32_t nl = std::max<uint32_t>(16, log2ceil(std::max<uint64_t>(need, 1) * 2));
-    int rc;
-    if (!h->t.ovf_lo || h->ovf_used_ub == 0) { rc = ovf_alloc(h, h->t, nl); h->ovf_dirty = false; return rc; }
-    if ((rc = sk_ctrs_init(h))) return rc;
-    KdfTable nt = h->t;
-    nt.ovf_lo = nullptr; nt.ovf_cnt = nullptr;
-    if ((rc = ovf_alloc(h, nt, nl))) return rc;
-    HIPCHK(h, hipMemsetAsync(h->sk_ctrs + 8, 0, 4, h->stream));
-    const uint64_t ocap = 1ull << h->t.ovf_log2cap;
-    hipLaunchKernelGGL(sk_ovf_rehash_kernel, dim3((unsigned)((ocap + 255) / 256)), dim3(256), 0, h->stream,
-                       (const uint64_t *)h->t.ovf_lo, (const uint32_t *)h->t.ovf_cnt, ocap, nt, h->ctl, h->sk_ctrs + 8);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(h->sk_ctrs_host + 8, h->sk_ctrs + 8, 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    (void)hipFree(h->t.ovf_lo); (void)hipFree(h->t.ovf_cnt);
-    h->t.ovf_lo = nt.ovf_lo; h->t.ovf_cnt = nt.ovf_cnt; h->t.ovf_log2cap = nl;
-    h->ovf_used_ub = h->sk_ctrs_host[8];              // exact now
-    return KDF_OK;
-}
-
-static SkPlan sk_make_plan(const KdfTable &t, int k) {
-    SkPlan p{};
-    p.log2cap = t.log2cap; p.bucket_bits = t.bucket_bits; p.k = (uint32_t)k;
-    const uint32_t nb_bits = t.log2cap - t.bucket_bits;
-    p.c2 = std::min<uint32_t>(SK_C2_MAX, nb_bits);
-    p.c1 = std::min<uint32_t>(SK_C1_MAX, nb_bits - p.c2);
-    p.sub_bits = nb_bits - p.c1 - p.c2;
-    p.goff_stride = (1u << p.c2) + 1;
-    return p;
-}
-
-// the logically EMPTY table becomes minimizer-bucketed (2048-slot buckets: three bucket workgroups per CU)
-static int sk_enter(kdf_engine *h) {
-    if (h->t.sk) return KDF_OK;
-    h->t.sk = 1; h->t.k = (uint32_t)h->k;
-    h->t.sk_assign = nullptr; h->t.sk_c1 = h->t.sk_c2 = 0;
-    h->t.bucket_bits = std::min<uint32_t>(h->t.log2cap, SK_BUCKET_BITS);
-    h->ovf_used_ub = 0;
-    int rc = ovf_alloc(h, h->t, h->t.ovf_lo ? h->t.ovf_log2cap : 16);
-    h->ovf_dirty = false;
-    return rc;
-}
-static void sk_leave(kdf_engine *h) {                  // back to the hash layout (the table must be logically empty)
-    if (!h->t.sk) return;
-    h->t.sk = 0; h->t.sk_assign = nullptr; h->t.sk_c1 = h->t.sk_c2 = 0;
-    h->t.bucket_bits = std::min<uint32_t>(h->t.log2cap, 12);
-    h->ovf_used_ub = 0; h->ovf_dirty = true;
-}
-
-
-// the balanced minimizer -> bucket table for geometry (c1, c2), from weights already accumulated in h->sk_weights
-static int sk_assign_alloc(kdf_engine *h) {
-    if (!h->sk_assign) HIPCHK(h, hipMalloc((void **)&h->sk_assign, (size_t)(1u << 24) * 2));
-    if (!h->sk_weights) HIPCHK(h, hipMalloc((void **)&h->sk_weights, (size_t)(1u << 24) * 4));
-    return KDF_OK;
-}
-static int sk_assign_deal(kdf_engine *h, uint32_t c1, uint32_t c2) {
-    if (!h->sk_attrs_set[1]) {
-        HIPCHK(h, hipFuncSetAttribute((const void *)sk_assign_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
-        h->sk_attrs_set[1] = true;
-    }
-    hipLaunchKernelGGL(sk_assign_kernel, dim3(1u << c1), dim3(1024), 16384 * 8, h->stream, (const uint32_t *)h->sk_weights, h->sk_assign, c1, c2);
-    HIPCHK(h, hipGetLastError());
-    h->sk_assign_c1 = c1; h->sk_assign_c2 = c2;
-    return KDF_OK;
-}
-static bool sk_want_assign(const kdf_engine *h, const SkPlan &p) { return h->opt_sk_balance && p.c1 >= 7 && p.sub_bits == 0; }
-
-template <int K>
-static int sk_launch_extract(kdf_engine *h, unsigned grid, size_t lds, const uint64_t *d_packed, const uint64_t *d_invalid,
-                             uint64_t n_bases, const SkPlan &plan, const SkScratch &s, uint32_t slabs_per_wg) {
-    if (!h->sk_attrs_set[K]) {
-        HIPCHK(h, hipFuncSetAttribute((const void *)sk_extract_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        h->sk_attrs_set[K] = true;
-    }
-    hipLaunchKernelGGL(sk_extract_kernel<K>, dim3(grid), dim3(SK_THREADS), lds, h->stream, d_packed, d_invalid, n_bases, plan, s, slabs_per_wg);
-    return KDF_OK;
-}
-
-static int sk_spill_flush(kdf_engine *h, const SkScratch &s, uint64_t n_spill) {
-    if (n_spill == 0) return KDF_OK;
-    int rc = ovf_ensure(h, n_spill);
-    if (rc) return rc;
-    hipLaunchKernelGGL(sk_spill_insert_kernel, dim3((unsigned)((n_spill + 255) / 256)), dim3(256), 0, h->stream, s, h->t, h->ctl);
-    HIPCHK(h, hipGetLastError());
-    h->ovf_used_ub += n_spill;
-    h->stat_sk_spills += n_spill;
-    return KDF_OK;
-}
-
-// one pass of the super-k-mer pipeline over a device-resident stream (insert mode, SK-layout table).
-// dense: size the chunk pool for one record per position (after a pass ran out of chunks).
-static int sk_pass(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases, bool dense) {
-    if (n_bases == 0) return KDF_OK;
-    int rc;
-    if ((rc = sk_ctrs_init(h))) return rc;
-    SkPlan plan = sk_make_plan(h->t, h->k);
-    plan.key_parts = h->t.key_parts; plan.key_part = h->t.key_part; plan.dbg = h->opt_debug_flags;
-    const uint32_t nbins = 1u << plan.c1;
-    const uint64_t n_slabs = (n_bases + SK_SLAB - 1) / SK_SLAB;
-    uint32_t grid_s1 = (uint32_t)std::min<uint64_t>(n_slabs, (uint64_t)h->n_cu);
-    const uint32_t slabs_per_wg = (uint32_t)((n_slabs + grid_s1 - 1) / grid_s1);
-    grid_s1 = (uint32_t)((n_slabs + slabs_per_wg - 1) / slabs_per_wg);
-    const uint64_t W = (uint64_t)h->k - KDF_SK_M + 1;
-    const uint64_t rec_cap = dense ? n_bases + 65536 : std::min<uint64_t>(n_bases, n_bases * 3 / (W + 1)) + 65536;
-    const uint64_t max_chunks64 = rec_cap / SK_CHUNK + (uint64_t)grid_s1 * nbins + 64;
-    const uint64_t max_groups64 = max_chunks64 / SK_GROUP + nbins + 1;
-    if (max_groups64 * SK_GREC >= (1ull << 32)) return fail(h, KDF_ERR_INVALID, "super-k-mer pass: %llu positions are too many for one pass", (unsigned long long)n_bases);
-    const uint64_t nb_table = 1ull << (plan.c1 + plan.c2 + plan.sub_bits);
-    SkScratch s{};
-    s.max_chunks = (uint32_t)max_chunks64; s.max_groups = (uint32_t)max_groups64;
-    if ((rc = sk_reserve(h, SKB_CHUNKS, max_chunks64 * SK_CHUNK * sizeof(SkRec)))) return rc;
-    if ((rc = sk_reserve(h, SKB_CBIN, max_chunks64 * 4))) return rc;
-    if ((rc = sk_reserve(h, SKB_CPOS, max_chunks64 * 4))) return rc;
-    if ((rc = sk_reserve(h, SKB_CFILL, max_chunks64 * 4))) return rc;
-    if ((rc = sk_reserve(h, SKB_CLIST, max_chunks64 * 4))) return rc;
-    const size_t small_words = 3 * ((size_t)(1 << SK_C1_MAX) + 1);
-    if ((rc = sk_reserve(h, SKB_SMALL, small_words * 4))) return rc;
-    if ((rc = sk_reserve(h, SKB_SORTED, max_groups64 * SK_GREC * sizeof(SkRec)))) return rc;
-    if ((rc = sk_reserve(h, SKB_GOFF, max_groups64 * plan.goff_stride * 4))) return rc;
-    const size_t failed_bytes = (size_t)((nb_table + 31) / 32) * 4;
-    if ((rc = sk_reserve(h, SKB_FAILED, failed_bytes))) return rc;
-    const uint32_t sp_cap0 = 1u << 20;
-    if (h->sk_bytes[SKB_SPKEY] < (size_t)sp_cap0 * 8) { if ((rc = sk_reserve(h, SKB_SPKEY, (size_t)sp_cap0 * 8))) return rc; }
-    if (h->sk_bytes[SKB_SPCNT] < (size_t)sp_cap0 * 4) { if ((rc = sk_reserve(h, SKB_SPCNT, (size_t)sp_cap0 * 4))) return rc; }
-    s.chunks = (SkRec *)h->sk_buf[SKB_CHUNKS];
-    s.chunk_bin = (uint32_t *)h->sk_buf[SKB_CBIN]; s.chunk_pos = (uint32_t *)h->sk_buf[SKB_CPOS];
-    s.chunk_fill = (uint32_t *)h->sk_buf[SKB_CFILL]; s.chunk_list = (uint32_t *)h->sk_buf[SKB_CLIST];
-    s.bin_nchunks = (uint32_t *)h->sk_buf[SKB_SMALL];
-    s.bin_chunk_start = s.bin_nchunks + (1 << SK_C1_MAX) + 1;
-    s.group_first = s.bin_chunk_start + (1 << SK_C1_MAX) + 1;
-    s.sorted = (SkRec *)h->sk_buf[SKB_SORTED]; s.goff = (uint32_t *)h->sk_buf[SKB_GOFF];
-    s.failed = (uint32_t *)h->sk_buf[SKB_FAILED];
-    s.sp_key = (uint64_t *)h->sk_buf[SKB_SPKEY]; s.sp_cnt = (uint32_t *)h->sk_buf[SKB_SPCNT];
-    s.sp_cap = (uint32_t)std::min<uint64_t>(h->sk_bytes[SKB_SPKEY] / 8, h->sk_bytes[SKB_SPCNT] / 4);
-    s.ctrs = h->sk_ctrs;
-    HIPCHK(h, hipMemsetAsync(h->sk_ctrs, 0, SKC_N * 4, h->stream));
-    HIPCHK(h, hipMemsetAsync(s.bin_nchunks, 0, small_words * 4, h->stream));
-    HIPCHK(h, hipMemsetAsync(s.failed, 0, failed_bytes, h->stream));
-    HIPCHK(h, hipMemsetAsync(s.sp_cnt, 0, (size_t)s.sp_cap * 4, h->stream));      // a zero count marks a hole in the spill list
-
-    const size_t lds_s1 = (size_t)SK_WPT * SK_THREADS * 4 + (size_t)SK_CAP * 20 + (size_t)(5 * (1 << SK_C1_MAX) + 2 + 40) * 4 + (size_t)(SK_WP + SK_WM) * 8
-                          + (size_t)(2 * SK_THREADS + 4) * 2 + 16;
-    const size_t lds_s2 = (size_t)SK_GREC * 16 + (size_t)(2 * (1 << SK_C2_MAX) + 40 + 2 * SK_GROUP) * 4;
-    const size_t lds_s3 = sk_bucket_lds(plan.bucket_bits);
-    if (!h->sk_attrs_set[0]) {
-        HIPCHK(h, hipFuncSetAttribute((const void *)sk_finesort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s2));
-        HIPCHK(h, hipFuncSetAttribute((const void *)sk_bucket_kernel<SK_MODE_COUNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sk_bucket_lds(12)));
-        HIPCHK(h, hipFuncSetAttribute((const void *)sk_bucket_kernel<SK_MODE_REPLAY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sk_bucket_lds(12)));
-        h->sk_attrs_set[0] = true;
-    }
+    KbScratch s;
+    if ((rc = kb_scratch(h, s))) return rc;
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     std::vector<hipEvent_t> sev;
     auto stamp = [&]() { if (h->prof) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, h->stream); sev.push_back(e); } };
     if (h->prof) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, h->stream); }
-    stamp();
-    switch (h->k) {
-#define SK_CASE(KK) case KK: rc = sk_launch_extract<KK>(h, grid_s1, lds_s1, d_packed, d_invalid, n_bases, plan, s, slabs_per_wg); break;
-        SK_CASE(16) SK_CASE(17) SK_CASE(18) SK_CASE(19) SK_CASE(20) SK_CASE(21) SK_CASE(22) SK_CASE(23) SK_CASE(24)
-        SK_CASE(25) SK_CASE(26) SK_CASE(27) SK_CASE(28) SK_CASE(29) SK_CASE(30) SK_CASE(31) SK_CASE(32)
-#undef SK_CASE
-        default: rc = fail(h, KDF_ERR_INVALID, "super-k-mer path: k=%d outside %d..32", h->k, SK_MIN_K);
-    }
-    if (rc) return rc;
-    if (h->distinct == 0 && h->ovf_used_ub == 0 && !h->t.sk_assign && sk_want_assign(h, plan)) {
-        // first pass of a table generation: fix the minimizer -> bucket assignment.  A table of this geometry dealt
-        // earlier (an engine that is cleared and refilled) is simply used again; else it is dealt from the weights
-        // of this batch's records (a sample of the chunks S1 has just written).
-        if (!(h->sk_assign && h->sk_assign_c1 == plan.c1 && h->sk_assign_c2 == plan.c2)) {
-            if ((rc = sk_assign_alloc(h))) return rc;
-            HIPCHK(h, hipMemsetAsync(h->sk_weights, 0, (size_t)(1u << 24) * 4, h->stream));
-            hipLaunchKernelGGL(sk_weight_records_kernel, dim3((unsigned)max_chunks64), dim3(256), 0, h->stream, s, h->sk_weights);
-            if ((rc = sk_assign_deal(h, plan.c1, plan.c2))) return rc;
-        }
-        h->t.sk_assign = h->sk_assign; h->t.sk_c1 = plan.c1; h->t.sk_c2 = plan.c2;
-    }
-    plan.assign = h->t.sk_assign;
-    stamp();                                                   // end of S1
-    hipLaunchKernelGGL(sk_binscan_kernel, dim3(1), dim3(1024), 0, h->stream, plan, s);
-    hipLaunchKernelGGL(sk_chunklist_kernel, dim3((unsigned)((max_chunks64 + 255) / 256)), dim3(256), 0, h->stream, s);
-    stamp();                                                   // end of K1
-    hipLaunchKernelGGL(sk_finesort_kernel, dim3(s.max_groups), dim3(SK_THREADS), lds_s2, h->stream, plan, s);
-    stamp();                                                   // end of S2
-    const int nonempty = h->lazy_empty ? 0 : 1;
-    hipLaunchKernelGGL(sk_bucket_kernel<SK_MODE_COUNT>, dim3((unsigned)nb_table), dim3(SK_C_THREADS), lds_s3, h->stream, plan, s, h->t, h->ctl, nonempty);
+    stamp();                                                   // start of A0
+
+    const uint32_t pass_idx = h->n_pass;
+    const bool sliced = plan.key_parts > 1;
+    if (sliced) hipLaunchKernelGGL((kb_hist1_kernel<KW, true>), dim3(grid_a), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
+    else hipLaunchKernelGGL((kb_hist1_kernel<KW, false>), dim3(grid_a), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
+    hipLaunchKernelGGL(kb_colscan_kernel, dim3(nbins), dim3(256), 0, h->stream, plan, s, (uint32_t)grid_a);
+    hipLaunchKernelGGL(kb_scan1_kernel, dim3(1), dim3(KB_THREADS), 0, h->stream, plan, s, pass_idx, (unsigned long long)h->ring_used,
+                       (unsigned long long)h->rows_used, (uint32_t)CHUNK, h->ctl);
+    HIPCHK(h, hipGetLastError());
+    stamp();                                                   // end of A0 (+ scans)
+    // No host round trip here: the pass's share of the ring is sized for one entry per position and B is launched over the
+    // largest number of chunks the bins can have (its workgroups beyond the real count leave at once).
+    const uint64_t n_chunks_max = n_entries_max / CHUNK + (uint64_t)nbins + 1;
+    if (sliced) hipLaunchKernelGGL((kb_scatter1_kernel<KW, true>), dim3(grid_a), dim3(KB_THREADS), lds_a1, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, pass_idx, slabs_per_wg);
+    else hipLaunchKernelGGL((kb_scatter1_kernel<KW, false>), dim3(grid_a), dim3(KB_THREADS), lds_a1, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, pass_idx, slabs_per_wg);
+    stamp();                                                   // end of A1
+    hipLaunchKernelGGL(kb_finesort_kernel<KW>, dim3((unsigned)n_chunks_max), dim3(KB_THREADS), lds_b, h->stream, plan, s, pass_idx);
+    stamp();                                                   // end of B
     HIPCHK(h, hipGetLastError());
     if (h->prof) {
-        stamp();                                               // end of S3
         (void)hipEventRecord(e1, h->stream);
         h->prof_ev.emplace_back(e0, e1);
-        h->prof_tiles.push_back((n_bases + KDF_TILE - 1) / KDF_TILE);
+        h->prof_tiles.push_back(n_tiles);
         h->prof_stage_ev.push_back(sev);
     }
-    HIPCHK(h, hipMemcpyAsync(h->sk_ctrs_host, h->sk_ctrs, SKC_N * 4, hipMemcpyDeviceToHost, h->stream));
-    bool full = false;
-    if ((rc = ctl_sync(h, &full))) return rc;
-    const uint32_t *c = h->sk_ctrs_host;
-    for (int i = 0; i < 6; ++i) h->stat_dbg[i] = c[8 + i];
-    if (c[SKC_EXHAUSTED]) { h->stat_sk_fallbacks++; return SK_RC_EXHAUSTED; }          // nothing was inserted
-    h->stat_sk_passes++;
-    h->lazy_empty = false;
-    if (c[SKC_BADNK]) return fail(h, KDF_ERR_STATE, "super-k-mer pass: a record exceeded its window bound (internal error)");
-    if ((rc = sk_spill_flush(h, s, std::min<uint64_t>(c[SKC_SPILL], s.sp_cap)))) return rc;
-    const uint64_t n_failed = c[SKC_FAILED];
-    if (n_failed) {
-        // buckets whose spills did not fit their queue / the list: they are untouched in HBM.  Replay exactly those
-        // with a spill list that holds the worst case (every window of the pass a spill).
-        h->stat_sk_failed += n_failed;
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        const uint64_t worst = std::min<uint64_t>(n_bases, 0xFFFFFFF0ull);
-        if ((rc = sk_reserve(h, SKB_SPKEY, worst * 8))) return rc;
-        if ((rc = sk_reserve(h, SKB_SPCNT, worst * 4))) return rc;
-        s.sp_key = (uint64_t *)h->sk_buf[SKB_SPKEY]; s.sp_cnt = (uint32_t *)h->sk_buf[SKB_SPCNT];
-        s.sp_cap = (uint32_t)worst;
-        HIPCHK(h, hipMemsetAsync(h->sk_ctrs + SKC_SPILL, 0, 4, h->stream));
-        hipLaunchKernelGGL(sk_bucket_kernel<SK_MODE_REPLAY>, dim3((unsigned)nb_table), dim3(SK_C_THREADS), lds_s3, h->stream, plan, s, h->t, h->ctl, 1);
-        HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipMemcpyAsync(h->sk_ctrs_host, h->sk_ctrs, SKC_N * 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (c[SKC_SPILL_LOST]) return fail(h, KDF_ERR_STATE, "super-k-mer replay: spill list overflow (internal error)");
-        if ((rc = sk_spill_flush(h, s, std::min<uint64_t>(c[SKC_SPILL], s.sp_cap)))) return rc;
-    }
-    if (c[SKC_SPILL] || n_failed) {
-        if ((rc = ctl_sync(h, &full))) return rc;
-        if (full) return fail(h, KDF_ERR_TABLE_FULL, "super-k-mer pass: overflow table full (internal error)");
-    }
+    h->n_pass++;
+    h->ring_used += n_entries_max; h->rows_used += n_chunks_max;
+    h->pend_positions += n_entries_max;
+    h->stat_binned_passes++;
+    h->last_path = 1;
     return KDF_OK;
 }
 
-// the super-k-mer path over a stream of any length; a range whose chunk pool ran out is redone with a pool sized for
-// one record per position (small ranges) or in halves
-static int sk_passes(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases, int depth = 0) {
-    const uint64_t step = std::min<uint64_t>(h->opt_binned_max_positions, 1ull << 31);
+// partition a stream of any length: passes of at most opt_binned_max_positions
+// positions, each starting on a tile boundary (windows that start in a pass may read on
+// into the next tiles: the stream is one buffer)
+static int kb_partition_stream(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases, bool filtered) {
+    const uint64_t step = h->opt_binned_max_positions;
     for (uint64_t off = 0; off < n_bases; off += step) {
         const uint64_t len = std::min<uint64_t>(step, n_bases - off);
         const uint64_t *p = d_packed + off / 32, *m = d_invalid + off / 64;
-        int rc = sk_pass(h, p, m, len, false);
-        if (rc == SK_RC_EXHAUSTED) {
-            if (len <= (1ull << 24)) rc = sk_pass(h, p, m, len, true);
-            else if (depth > 40) rc = fail(h, KDF_ERR_STATE, "super-k-mer path: chunk pool exhausted");
-            else {
-                const uint64_t half = (len / 2 + 63) / 64 * 64;
-                const uint64_t save = h->opt_binned_max_positions;
-                h->opt_binned_max_positions = half;
-                rc = sk_passes(h, p, m, len, depth + 1);
-                h->opt_binned_max_positions = save;
-            }
-            if (rc == SK_RC_EXHAUSTED) rc = fail(h, KDF_ERR_STATE, "super-k-mer path: chunk pool exhausted");
-        }
+        int rc = h->kw == 1 ? kb_partition<1>(h, p, m, len, filtered) : kb_partition<2>(h, p, m, len, filtered);
         if (rc) return rc;
-        if (off + step < n_bases)
-            while (h->distinct * 10 > h->cap * 7)
-                if ((rc = table_rehash(h, h->t.log2cap + 1))) return rc;
     }
     return KDF_OK;
 }
 
-static bool use_sk(const kdf_engine *h, uint64_t n_bases) {
-    if (h->kw != 1 || h->k < SK_MIN_K || h->opt_hash_shift) return false;
-    if (h->t.sk) return true;                                   // an SK-layout table takes every batch through this path
-    if (h->filter_mode || h->distinct != 0) return false;       // layouts change only on an empty table
-    if (h->opt_force_path == 3) return true;
-    if (h->opt_force_path != 0) return false;
-    return h->opt_sk_auto && (uint32_t)h->k >= h->opt_sk_min_k && n_bases >= h->opt_binned_min_positions;
-}
-
-
-// (key, count) pairs resident in HBM into the live SK table: bucket first, the rest through the spill list
-static int sk_insert_pairs(kdf_engine *h, const uint64_t *d_lo, const uint32_t *d_cnt, uint64_t n, int skip_empty, uint64_t spill_room,
-                           SkScratch &s, bool reset_ctrs) {
+// Kernel C over every pending pass: the ring is applied to the table and emptied.
+static int kb_flush_ring(kdf_engine *h) {
+    if (h->n_pass == 0) return KDF_OK;
     int rc;
-    if ((rc = sk_ctrs_init(h))) return rc;
-    spill_room = std::min<uint64_t>(std::max<uint64_t>(spill_room, 1), 0xFFFFFFF0ull);
-    if ((rc = sk_reserve(h, SKB_SPKEY, spill_room * 8))) return rc;
-    if ((rc = sk_reserve(h, SKB_SPCNT, spill_room * 4))) return rc;
-    s.sp_key = (uint64_t *)h->sk_buf[SKB_SPKEY]; s.sp_cnt = (uint32_t *)h->sk_buf[SKB_SPCNT];
-    s.sp_cap = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(h->sk_bytes[SKB_SPKEY] / 8, h->sk_bytes[SKB_SPCNT] / 4), 0xFFFFFFF0ull);
-    s.ctrs = h->sk_ctrs;
-    if (reset_ctrs) HIPCHK(h, hipMemsetAsync(h->sk_ctrs, 0, SKC_N * 4, h->stream));
-    if (n) hipLaunchKernelGGL(sk_insert_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, d_lo, d_cnt, n, h->t, h->ctl, s, skip_empty);
+    KbScratch s;
+    if ((rc = kb_scratch(h, s))) return rc;
+    const bool filtered = h->pend_filtered;
+    // what the pending passes hold (entries, skew) and what the table holds now
+    HIPCHK(h, hipMemcpyAsync(h->kb_totals_host, s.totals, (16 + 2) * 8, hipMemcpyDeviceToHost, h->stream));
+    if ((rc = ctl_sync(h, nullptr))) return rc;
+    if (((unsigned int *)(h->kb_totals_host + 16))[0]) {
+        (void)kb_ring_reset(h);
+        return fail(h, KDF_ERR_STATE, "binned count: the read stream changed while it was being counted "
+                                      "(is another stream still writing it? synchronise before the call)");
+    }
+    const uint64_t n_entries = h->kb_totals_host[0];
+    const bool skewed = h->kb_totals_host[7] != 0 || (h->opt_debug_flags & 4096);          // (debug flag 4096 forces VAR 2: fuzzing)
+    const uint64_t distinct_before = h->distinct;
+    // Grow BEFORE the flush when the last flush's rate of new keys says the pending entries will not fit: growing now
+    // rehashes the smaller table, and kernel C resolves the extra bucket bits itself (sub_bits) -- no failed buckets, no
+    // replay through the global-atomic path.  (First flush of a table: the caller's capacity hint is trusted.)
+    if (!filtered && h->grow_ratio > 0.0) {
+        const double est = (double)h->distinct + h->grow_ratio * (double)n_entries;
+        while (est > 0.6 * (double)h->cap && h->t.log2cap < 40) {
+            if (h->lazy_empty) {                                  // nothing to carry over: a new table, still to be cleared
+                KdfTable nt;
+                if ((rc = table_alloc(h, h->t.log2cap + 1, nt, false))) break;       // (no room: kernel C will tell what really overflows)
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                table_free(h->t);
+                h->t = nt; h->t.key_parts = h->opt_key_parts; h->t.key_part = h->opt_key_part;
+                h->cap = 1ull << h->t.log2cap;
+            } else if ((rc = table_rehash(h, h->t.log2cap + 1))) { (void)hipGetLastError(); h->err.clear(); break; }
+        }
+    }
+    if (filtered && (rc = materialize(h))) return rc;
+    KbPlan plan = h->pend_plan;
+    plan.n_pass = h->n_pass; plan.dbg = h->opt_debug_flags;
+    plan.log2cap = h->t.log2cap; plan.bucket_bits = h->t.bucket_bits;
+    plan.sub_bits = (h->t.log2cap - h->t.bucket_bits) - plan.c1 - plan.c2;       // a table that grew since the partition: more sub-buckets
+    const uint64_t nb_table = 1ull << (plan.c1 + plan.c2 + plan.sub_bits);
+    const size_t failed_bytes = (size_t)((nb_table + 31) / 32) * 4;
+    if ((rc = kb_reserve(h, 3, failed_bytes))) return rc;
+    s.failed = (uint32_t *)h->kb_buf[3];
+    HIPCHK(h, hipMemsetAsync(s.failed, 0, failed_bytes, h->stream));
+    const int nonempty = h->lazy_empty ? 0 : 1;   // 0: kernel C rewrites every bucket (this IS the clear)
+    std::vector<hipEvent_t> sev;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->prof) {
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, h->stream);
+        hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, h->stream); sev.push_back(e);
+    }
+    const bool heavy = skewed && h->kw == 1 && !filtered && s.hv_ctr && plan.bucket_bits == 12 && plan.sub_bits == 0;
+    if (heavy) {
+        HIPCHK(h, hipMemsetAsync(s.hv_ctr, 0, (4 + 3 * KB_HV_MAX) * 4, h->stream));
+    }
+    by_width(h, [&](auto KWc) {
+        constexpr int KW = decltype(KWc)::value;
+        const size_t lds_c = KB_C_LDS(KW, plan.bucket_bits);
+#define KB_LV(M, V) hipLaunchKernelGGL((kb_bucket_kernel<KW, M, V>), dim3((unsigned)nb_table), dim3(KB_C_CT(KW)), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty)
+        if (filtered) { if (skewed) KB_LV(KB_MODE_FILTERED, 2); else KB_LV(KB_MODE_FILTERED, 1); }
+        else { if (skewed) KB_LV(KB_MODE_INSERT, 2); else KB_LV(KB_MODE_INSERT, 1); }
+#undef KB_LV
+        return 0;
+    });
+    if (heavy) {
+        // the buckets the skewed instantiation left aside
+        const size_t lds_h = ((size_t)12 << plan.bucket_bits) + KB_RI_LDS_BYTES;
+        hipLaunchKernelGGL(kb_heavy_slice_kernel, dim3(KB_HV_SLICES, KB_HV_MAX), dim3(256), lds_h, h->stream, plan, s);
+        hipLaunchKernelGGL(kb_heavy_combine_kernel, dim3(KB_HV_MAX), dim3(256), lds_h, h->stream, plan, s, h->t, h->ctl, nonempty);
+    }
     HIPCHK(h, hipGetLastError());
-    return KDF_OK;
-}
-static int sk_insert_finish(kdf_engine *h, SkScratch &s) {
-    HIPCHK(h, hipMemcpyAsync(h->sk_ctrs_host, h->sk_ctrs, SKC_N * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->sk_ctrs_host[SKC_SPILL_LOST]) return fail(h, KDF_ERR_STATE, "SK insert: spill list overflow (internal error)");
-    int rc = sk_spill_flush(h, s, std::min<uint64_t>(h->sk_ctrs_host[SKC_SPILL], s.sp_cap));
-    if (rc) return rc;
+    if (h->prof) {
+        hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, h->stream); sev.push_back(e);
+        (void)hipEventRecord(e1, h->stream);
+        h->prof_ev.emplace_back(e0, e1);
+        h->prof_tiles.push_back(0);                            // (its positions were counted with the partition passes)
+        h->prof_stage_ev.push_back(sev);
+    }
+    HIPCHK(h, hipMemcpyAsync(h->kb_totals_host, s.totals, (16 + 2) * 8, hipMemcpyDeviceToHost, h->stream));
     bool full = false;
     if ((rc = ctl_sync(h, &full))) return rc;
-    if (full) return fail(h, KDF_ERR_TABLE_FULL, "SK insert: overflow table full (internal error)");
-    return KDF_OK;
-}
-
-// grow an SK-layout table: a new table with more buckets (the minimizers are dealt out afresh by their order
-// value's top bits), every key of the old bucket array and of the old overflow array re-inserted
-static int sk_table_rehash(kdf_engine *h, uint32_t new_log2) {
-    int rc = ctl_sync(h, nullptr);
-    if (rc) return rc;
-    const uint64_t windows = h->windows, n_keys = h->lazy_empty ? 0 : h->distinct;
-    KdfTable nt;
-    rc = table_alloc(h, new_log2, nt);
-    if (rc) { table_free(nt); return rc; }
-    nt.sk = 1; nt.k = (uint32_t)h->k; nt.bucket_bits = std::min<uint32_t>(new_log2, SK_BUCKET_BITS);
-    nt.key_parts = h->opt_key_parts; nt.key_part = h->opt_key_part;
-    if ((rc = ovf_alloc(h, nt, std::max<uint32_t>(16, h->t.ovf_lo ? h->t.ovf_log2cap : 16)))) { table_free(nt); return rc; }
-    nt.sk_assign = nullptr; nt.sk_c1 = nt.sk_c2 = 0;
-    KdfTable old = h->t;
-    {
-        const SkPlan np = sk_make_plan(nt, h->k);
-        if (n_keys && sk_want_assign(h, np)) {
-            // the new geometry's assignment is dealt from the exact weights: one per key the old table holds
-            if ((rc = sk_assign_alloc(h))) { table_free(nt); return rc; }
-            HIPCHK(h, hipMemsetAsync(h->sk_weights, 0, (size_t)(1u << 24) * 4, h->stream));
-            const uint64_t oc = 1ull << old.log2cap;
-            hipLaunchKernelGGL(sk_weight_table_kernel, dim3((unsigned)((oc + 255) / 256)), dim3(256), 0, h->stream, (const uint64_t *)old.lo, oc, h->k, h->sk_weights);
-            if (old.ovf_lo && h->ovf_used_ub) {
-                const uint64_t vc = 1ull << old.ovf_log2cap;
-                hipLaunchKernelGGL(sk_weight_table_kernel, dim3((unsigned)((vc + 255) / 256)), dim3(256), 0, h->stream, (const uint64_t *)old.ovf_lo, vc, h->k, h->sk_weights);
-            }
-            if ((rc = sk_assign_deal(h, np.c1, np.c2))) { table_free(nt); return rc; }
-            nt.sk_assign = h->sk_assign; nt.sk_c1 = np.c1; nt.sk_c2 = np.c2;
-        }
-    }
-    h->t = nt; h->cap = 1ull << new_log2;
-    const uint64_t old_ovf_used = h->ovf_used_ub;
-    h->ovf_used_ub = 0;
-    if ((rc = ctl_reset(h, false))) return rc;
-    if (n_keys) {
-        SkScratch s{};
-        if ((rc = sk_insert_pairs(h, old.lo, old.cnt, 1ull << old.log2cap, 1, n_keys, s, true))) return rc;
-        if (old.ovf_lo && old_ovf_used)
-            if ((rc = sk_insert_pairs(h, old.ovf_lo, old.ovf_cnt, 1ull << old.ovf_log2cap, 1, n_keys, s, false))) return rc;
-        if ((rc = sk_insert_finish(h, s))) return rc;
-    } else {
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        h->distinct = 0;
-    }
+    h->stat_flushes++;
     h->lazy_empty = false;
-    table_free(old);
-    h->windows = windows;
-    HIPCHK(h, hipMemcpyAsync(&h->ctl->windows[0], &h->windows, 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->stat_heavy_buckets += h->kb_totals_host[4];
+    const uint64_t n_failed = h->kb_totals_host[2];
+    if (n_failed) {
+        if (filtered) { (void)kb_ring_reset(h); return fail(h, KDF_ERR_STATE, "binned count --if: a bucket failed (corrupt table?)"); }
+        // some buckets overflowed: they are untouched in HBM.  Grow the table so
+        // that even if every entry of the failed buckets were new the load stays
+        // <= 0.5, then replay exactly those buckets through the global-atomic path.
+        h->stat_replayed_buckets += n_failed;
+        const uint64_t worst = h->distinct + std::min<uint64_t>(n_entries, n_failed * ((n_entries / std::max<uint64_t>(nb_table, 1)) * 4 + 4096));
+        const uint32_t want = std::max<uint32_t>(h->t.log2cap + 1, cap_log2_for(worst));
+        if ((rc = table_rehash(h, want))) { (void)kb_ring_reset(h); return rc; }
+        if (h->kw == 1) hipLaunchKernelGGL(kb_replay_kernel<1>, dim3((unsigned)nb_table), dim3(256), 0, h->stream, plan, s, h->t, h->ctl);
+        else hipLaunchKernelGGL(kb_replay_kernel<2>, dim3((unsigned)nb_table), dim3(256), 0, h->stream, plan, s, h->t, h->ctl);
+        HIPCHK(h, hipGetLastError());
+        if ((rc = ctl_sync(h, &full))) { (void)kb_ring_reset(h); return rc; }
+        if (full) { (void)kb_ring_reset(h); return fail(h, KDF_ERR_TABLE_FULL, "binned count: bucket overflow during replay (capacity 2^%u)", h->t.log2cap); }
+    }
+    if (!filtered && n_entries >= 100000) h->grow_ratio = (double)(h->distinct - distinct_before) / (double)n_entries;
+    if ((rc = kb_ring_reset(h))) return rc;
+    // keep the load <= 0.7 for what comes next (a 2048-slot bucket then holds
+    // 1434 +- 38 keys: overflow, which is handled anyway, stays a rare event)
+    if (!filtered)
+        while (h->distinct * 10 > h->cap * 7)
+            if ((rc = table_rehash(h, h->t.log2cap + 1))) return rc;
     return KDF_OK;
 }
 
-static bool use_binned(const kdf_engine *h, uint64_t n_bases, bool filtered) {
+// can the binned pipeline work on this engine's table at all?
+static bool kb_eligible(const kdf_engine *h) {
     if (h->opt_hash_shift) return false;                       // an owner table: the bins assume home = top hash bits
     if (h->t.log2cap <= h->t.bucket_bits) return false;        // a single bucket: nothing to partition
-    if (h->opt_force_path == 1) return false;
+    return h->opt_force_path != 1;
+}
+
+// Is a flush of n_bases pending positions worth the binned pipeline?  Kernel C reads and rewrites EVERY bucket of the
+// table (0.5 ms per GB), whatever the pending passes hold; the direct kernels cost 0.056 ms per million positions whatever
+// the table.  Crossover (scratch/bigtable_probe.py): ~14 M positions per GB of table.
+static bool use_binned(const kdf_engine *h, uint64_t n_bases, bool filtered) {
+    if (!kb_eligible(h)) return false;
     if (h->opt_force_path == 2) return true;
     if (n_bases < h->opt_binned_min_positions) return false;
     if (filtered && h->t.log2cap < h->opt_binned_filtered_min_log2cap) return false;
-    // A binned pass reads and rewrites EVERY bucket of the table (0.5 ms per GB), whatever the batch holds; the direct
-    // kernels cost 0.056 ms per million positions whatever the table.  A streamed sample is many batches into one big
-    // table (2^26 positions each from _stream_bam): measured 52 ms binned against 3.5 ms direct per batch at 103 GB.
-    // Crossover (scratch/bigtable_probe.py): ~14 M positions per GB of table.
-    {
-        // (count --if through the binned path reads every bucket and rewrites its counts just the same.)
-        // (a table that was only `clear`ed: the binned pass would also be its clear, the direct path pays a memset first --
-        // 0.2 ms per GB -- which moves the crossover to ~8.6 M positions per GB)
-        const uint64_t table_bytes = h->cap * (uint64_t)(8 * h->kw + 4);
-        const uint64_t per = h->lazy_empty ? h->opt_binned_bytes_per_position * 5 / 3 : h->opt_binned_bytes_per_position;
-        if (n_bases * per < table_bytes) return false;
-    }
-    return true;
+    if (filtered && h->opt_defer) return true;                 // (more batches will follow before the counts are read: the rewrite is shared)
+    // (a table that was only `clear`ed: the binned flush is also its clear, the direct path pays a memset first --
+    // 0.2 ms per GB -- which moves the crossover to ~8.6 M positions per GB)
+    const uint64_t table_bytes = h->cap * (uint64_t)(8 * h->kw + 4);
+    const uint64_t per = h->lazy_empty ? h->opt_binned_bytes_per_position * 5 / 3 : h->opt_binned_bytes_per_position;
+    return n_bases * per >= table_bytes;
 }
 
-// insert-mode count over a device-resident stream.  The stream is walked in
+// insert-mode count through the global-atomic kernels.  The stream is walked in
 // chunks sized so that even if every position were a new key the table stays
 // at load <= 0.8; the table doubles when fewer than cap/8 positions fit.
-static int count_insert_dev(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases) {
-    if (h->filter_mode) return fail(h, KDF_ERR_STATE, "kdf_count_reads: a filter is loaded; call kdf_clear first");
-    h->sieve_valid = false;                          // new keys join the table: a sieve built from it earlier (scan) is stale
-    h->t.key_parts = h->opt_key_parts; h->t.key_part = h->opt_key_part;       // (tables are re-created by reserve / rehash: set per call)
+static int direct_insert(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases) {
     const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
-    if (h->opt_force_path == 3 && (h->kw != 1 || h->k < SK_MIN_K))
-        return fail(h, KDF_ERR_INVALID, "force_path 3 (super-k-mer) needs %d <= k <= 32", SK_MIN_K);
-    if (use_sk(h, n_bases)) {
-        int rc = sk_enter(h);
-        if (rc) return rc;
-        h->last_path = 2;
-        if ((rc = sk_passes(h, d_packed, d_invalid, n_bases))) return rc;
-        while (h->distinct * 10 > h->cap * 7)
-            if ((rc = table_rehash(h, h->t.log2cap + 1))) return rc;
-        return KDF_OK;
-    }
-    if (use_binned(h, n_bases, false)) {
-        h->last_path = 1;
-        int rc = kb_passes(h, d_packed, d_invalid, n_bases, false);
-        if (rc) return rc;
-        // keep the load <= 0.7 for the next batch (a 2048-slot bucket then holds
-        // 1434 +- 38 keys: overflow, which is handled anyway, stays a rare event)
-        while (h->distinct * 10 > h->cap * 7) {
-            if ((rc = table_rehash(h, h->t.log2cap + 1))) return rc;
-        }
-        return KDF_OK;
-    }
     { int rc0 = materialize(h); if (rc0) return rc0; }
     h->last_path = 0;
     uint64_t tile = 0;
@@ -1460,12 +1063,83 @@ static int count_insert_dev(kdf_engine *h, const uint64_t *d_packed, const uint6
     return KDF_OK;
 }
 
+// L1: append a batch to the pending stream (tile aligned; the copy forces the mask bits past n_bases to "invalid")
+static int l1_append(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases) {
+    const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
+    if (h->l1_tiles + n_tiles > h->l1_cap_tiles) {
+        // grow (the pending stream moves): up to the size at which it is partitioned anyway
+        const uint64_t target = std::max<uint64_t>((h->opt_l1_positions + h->opt_l1_direct_positions) / KDF_TILE + 1, h->l1_tiles + n_tiles);
+        const uint64_t cap = std::min<uint64_t>(target, std::max<uint64_t>({2 * h->l1_cap_tiles, 4 * (h->l1_tiles + n_tiles), (uint64_t)1 << 18}));
+        uint64_t *np = nullptr, *nm = nullptr;
+        HIPCHK(h, hipMalloc((void **)&np, (cap * 2 + 4) * 8));
+        hipError_t e = hipMalloc((void **)&nm, (cap + 2) * 8);
+        if (e != hipSuccess) { (void)hipFree(np); (void)hipGetLastError(); return fail(h, KDF_ERR_NOMEM, "pending stream: %s", hipGetErrorString(e)); }
+        if (h->l1_tiles) {
+            HIPCHK(h, hipMemcpyAsync(np, h->l1_packed, (h->l1_tiles * 2 + 4) * 8, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(nm, h->l1_mask, (h->l1_tiles + 2) * 8, hipMemcpyDeviceToDevice, h->stream));
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->l1_packed) (void)hipFree(h->l1_packed);
+        if (h->l1_mask) (void)hipFree(h->l1_mask);
+        h->l1_packed = np; h->l1_mask = nm; h->l1_cap_tiles = cap;
+    }
+    const unsigned blocks = (unsigned)((2 * n_tiles + 4 + 255) / 256);
+    hipLaunchKernelGGL(kb_append_kernel, dim3(blocks), dim3(256), 0, h->stream, h->l1_packed + 2 * h->l1_tiles, h->l1_mask + h->l1_tiles,
+                       d_packed, d_invalid, n_bases);
+    HIPCHK(h, hipGetLastError());
+    h->l1_tiles += n_tiles;
+    return KDF_OK;
+}
+
+// everything pending (the concatenated small batches, the partitioned passes) goes into the table
+static int pending_flush(kdf_engine *h) {
+    int rc;
+    if (h->l1_tiles) {
+        const uint64_t n = h->l1_tiles * KDF_TILE;
+        h->l1_tiles = 0;
+        if (h->n_pass > 0 ? kb_eligible(h) : use_binned(h, n, false)) rc = kb_partition_stream(h, h->l1_packed, h->l1_mask, n, false);
+        else rc = direct_insert(h, h->l1_packed, h->l1_mask, n);
+        if (rc) return rc;
+    }
+    return kb_flush_ring(h);
+}
+// ... or is forgotten (kdf_clear)
+static int pending_drop(kdf_engine *h) {
+    h->l1_tiles = 0;
+    return kb_ring_reset(h);
+}
+
+// insert-mode count over a device-resident stream
+static int count_insert_dev(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases) {
+    if (h->filter_mode) return fail(h, KDF_ERR_STATE, "kdf_count_reads: a filter is loaded; call kdf_clear first");
+    h->sieve_valid = false;                          // new keys join the table: a sieve built from it earlier (scan) is stale
+    h->t.key_parts = h->opt_key_parts; h->t.key_part = h->opt_key_part;       // (tables are re-created by reserve / rehash: set per call)
+    if (n_bases == 0) return KDF_OK;
+    int rc;
+    if (h->opt_force_path == 2 && kb_eligible(h)) rc = kb_partition_stream(h, d_packed, d_invalid, n_bases, false);
+    else if (!kb_eligible(h) || h->opt_force_path == 1) {
+        if ((rc = pending_flush(h))) return rc;
+        rc = direct_insert(h, d_packed, d_invalid, n_bases);
+    } else if (n_bases >= h->opt_l1_direct_positions) rc = kb_partition_stream(h, d_packed, d_invalid, n_bases, false);   // big enough by itself
+    else {
+        rc = l1_append(h, d_packed, d_invalid, n_bases);
+        if (!rc && h->l1_tiles * KDF_TILE >= h->opt_l1_positions) {
+            const uint64_t n = h->l1_tiles * KDF_TILE;
+            h->l1_tiles = 0;
+            rc = kb_partition_stream(h, h->l1_packed, h->l1_mask, n, false);
+        }
+    }
+    if (rc) return rc;
+    if (!h->opt_defer) return pending_flush(h);
+    return KDF_OK;
+}
+
 static int count_filtered_dev(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases) {
     if (!h->filter_mode) return fail(h, KDF_ERR_STATE, "kdf_count_reads_filtered: no filter loaded (kdf_load_filter)");
     const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
     if (n_tiles == 0) return KDF_OK;
     { int rc0 = materialize(h); if (rc0) return rc0; }
-    if (h->sieve_valid && !h->t.sk && (h->opt_force_path == 0 || h->opt_force_path == 4)) {
+    if (h->sieve_valid && (h->opt_force_path == 0 || h->opt_force_path == 4)) {
         // persistent workgroups over slabs of 1024 x WPT positions
         const int WPT = h->kw == 1 ? KbCfg<1>::WPT : KbCfg<2>::WPT;
         const uint64_t tiles_per_slab = KB_THREADS / (64 / WPT);
@@ -1487,7 +1161,12 @@ static int count_filtered_dev(kdf_engine *h, const uint64_t *d_packed, const uin
         return KDF_OK;
     }
     if (h->opt_force_path == 4) return fail(h, KDF_ERR_STATE, "force_path 4 (sieve): no sieve for this filter (it would not fit the caches, or keys were added after kdf_load_filter)");
-    if (use_binned(h, n_bases, true)) { h->last_path = 1; return kb_passes(h, d_packed, d_invalid, n_bases, true); }
+    if (use_binned(h, n_bases, true)) {
+        int rc = kb_partition_stream(h, d_packed, d_invalid, n_bases, true);
+        if (!rc && !h->opt_defer) rc = kb_flush_ring(h);
+        return rc;
+    }
+    { int rc0 = kb_flush_ring(h); if (rc0) return rc0; }           // (binned --if passes pending from earlier batches)
     h->last_path = 0;
     launch_stream<MODE_FILTERED>(h, d_packed, d_invalid, 0, n_tiles, nullptr);
     HIPCHK(h, hipGetLastError());
@@ -1542,6 +1221,7 @@ int kdf_create(int device, int k, uint64_t capacity_hint, kdf_engine **out) {
     auto bail = [&](int rc) { g_err = h->err; kdf_destroy(h); return rc; };
     if ((e = hipSetDevice(device)) != hipSuccess) { h->err = hipGetErrorString(e); return bail(KDF_ERR_HIP); }
     { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) h->n_cu = ncu; }
+    { size_t f = 0, tt = 0; if (hipMemGetInfo(&f, &tt) == hipSuccess) h->dev_total_bytes = tt; else (void)hipGetLastError(); }
     if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) { h->err = hipGetErrorString(e); return bail(KDF_ERR_HIP); }
     h->stream = h->own_stream;
     if ((e = hipMalloc((void **)&h->ctl, sizeof(KdfCtl))) != hipSuccess) { h->err = hipGetErrorString(e); return bail(KDF_ERR_NOMEM); }
@@ -1565,8 +1245,9 @@ void kdf_destroy(kdf_engine *h) {
     prof_collect(h);
     for (int i = 0; i < 4; ++i) if (h->stage[i]) (void)hipFree(h->stage[i]);
     for (int i = 0; i < 6; ++i) if (h->kb_buf[i]) (void)hipFree(h->kb_buf[i]);
-    for (int i = 0; i < 16; ++i) if (h->sk_buf[i]) (void)hipFree(h->sk_buf[i]);
-    for (int i = 0; i < 8; ++i) if (h->kp_buf[i]) (void)hipFree(h->kp_buf[i]);
+    if (h->l1_packed) (void)hipFree(h->l1_packed);
+    if (h->l1_mask) (void)hipFree(h->l1_mask);
+    if (h->kb_pass) (void)hipFree(h->kb_pass);
     if (h->merge_buf) (void)hipFree(h->merge_buf);
     if (h->kb_heavy) (void)hipFree(h->kb_heavy);
     for (int sl = 0; sl < 2; ++sl) {
@@ -1576,10 +1257,6 @@ void kdf_destroy(kdf_engine *h) {
     }
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->sieve) (void)hipFree(h->sieve);
-    if (h->sk_assign) (void)hipFree(h->sk_assign);
-    if (h->sk_weights) (void)hipFree(h->sk_weights);
-    if (h->sk_ctrs) (void)hipFree(h->sk_ctrs);
-    if (h->sk_ctrs_host) (void)hipHostFree(h->sk_ctrs_host);
     if (h->kb_small) (void)hipFree(h->kb_small);
     if (h->kb_totals_host) (void)hipHostFree(h->kb_totals_host);
     if (h->ctl) (void)hipFree(h->ctl);
@@ -1591,6 +1268,7 @@ void kdf_destroy(kdf_engine *h) {
 
 int kdf_set_stream(kdf_engine *h, void *hip_stream) {
     if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    { int rcf = pending_flush(h); if (rcf) return rcf; }          // (pending passes were enqueued on the old stream)
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     return KDF_OK;
@@ -1611,13 +1289,15 @@ int kdf_clear(kdf_engine *h) {
     if (rc) return rc;
     h->distinct = 0; h->windows = 0; h->filter_mode = false;
     h->lazy_empty = true; h->sieve_valid = false;
-    sk_leave(h);                  // layouts are chosen per table generation: the next count decides again
+    h->grow_ratio = 0.0;
+    if ((rc = pending_drop(h))) return rc;     // what was counted but not yet applied is dropped with the rest
     return KDF_OK;
 }
 
 int kdf_reserve(kdf_engine *h, uint64_t n_keys) {
     if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcf = pending_flush(h); if (rcf) return rcf; }
     const uint32_t want = cap_log2_for(std::max(n_keys, h->distinct));
     if (want <= h->t.log2cap) return KDF_OK;
     int rc = ctl_sync(h, nullptr);
@@ -1628,6 +1308,7 @@ int kdf_reserve(kdf_engine *h, uint64_t n_keys) {
 int kdf_stats(kdf_engine *h, uint64_t *capacity, uint64_t *distinct, uint64_t *windows) {
     if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcf = pending_flush(h); if (rcf) return rcf; }
     bool full = false;
     int rc = ctl_sync(h, &full);
     if (rc) return rc;
@@ -1636,6 +1317,12 @@ int kdf_stats(kdf_engine *h, uint64_t *capacity, uint64_t *distinct, uint64_t *w
     if (windows) *windows = h->windows;
     if (full) return fail(h, KDF_ERR_TABLE_FULL, "a bucket overflowed during an earlier call");
     return KDF_OK;
+}
+
+int kdf_flush(kdf_engine *h) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    HIPCHK(h, hipSetDevice(h->device));
+    return pending_flush(h);
 }
 
 int kdf_count_reads_dev(kdf_engine *h, const void *d_packed, const void *d_invalid, uint64_t n_bases) {
@@ -1720,6 +1407,10 @@ int kdf_count_uploaded(kdf_engine *h, int slot, int filtered) {
     const uint64_t n = h->up_n[slot];
     if (n == 0) return KDF_OK;
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->up_done[slot], 0));
+    // The HOST waits for the copy as well: the caller recycles its (pinned) source buffer as soon as this call returns,
+    // and a filtered count returns without any host synchronisation.  The copy was issued a whole batch ago and has
+    // normally long finished.
+    HIPCHK(h, hipEventSynchronize(h->up_done[slot]));
     const uint64_t *dp = (const uint64_t *)h->up_buf[slot][0], *dm = (const uint64_t *)h->up_buf[slot][1];
     const int rc = filtered ? count_filtered_dev(h, dp, dm, n) : count_insert_dev(h, dp, dm, n);
     (void)hipEventRecord(h->use_done[slot], h->stream);
@@ -1758,6 +1449,7 @@ static int sieve_prepare(kdf_engine *h, uint64_t n) {
 static int load_filter_core(kdf_engine *h, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t n) {
     int rc;
     h->sieve_valid = false;
+    if ((rc = pending_drop(h))) return rc;            // the table becomes the filter: whatever was pending goes with the old contents
     // size the table for n keys at load <= 0.5, then start from empty
     const uint32_t want = cap_log2_for(n);
     if (want != h->t.log2cap) {
@@ -1766,7 +1458,7 @@ static int load_filter_core(kdf_engine *h, const uint64_t *d_lo, const uint64_t 
         if ((rc = table_alloc(h, want, h->t))) return rc;
         h->cap = 1ull << want;
         if ((rc = ctl_reset(h, false))) return rc;
-        h->distinct = 0; h->windows = 0; h->lazy_empty = false; h->filter_mode = false; h->ovf_used_ub = 0;
+        h->distinct = 0; h->windows = 0; h->lazy_empty = false; h->filter_mode = false;
     } else if ((rc = kdf_clear(h))) return rc;
     if ((rc = materialize(h))) return rc;
     h->filter_mode = true;
@@ -1774,10 +1466,10 @@ static int load_filter_core(kdf_engine *h, const uint64_t *d_lo, const uint64_t 
     if (n) {
         if (h->kw == 1)
             hipLaunchKernelGGL(kdf_insert_keys_kernel<1>, dim3(blocks), dim3(256), 0, h->stream,
-                               d_lo, (const uint64_t *)nullptr, (const uint32_t *)nullptr, n, h->t, h->ctl, 0);
+                               d_lo, (const uint64_t *)nullptr, (const uint32_t *)nullptr, n, h->t, h->ctl, 0, 0);
         else
             hipLaunchKernelGGL(kdf_insert_keys_kernel<2>, dim3(blocks), dim3(256), 0, h->stream,
-                               d_lo, d_hi, (const uint32_t *)nullptr, n, h->t, h->ctl, 0);
+                               d_lo, d_hi, (const uint32_t *)nullptr, n, h->t, h->ctl, 0, 0);
         HIPCHK(h, hipGetLastError());
         bool full = false;
         if ((rc = ctl_sync(h, &full))) return rc;
@@ -1818,10 +1510,10 @@ int kdf_load_filter_dev(kdf_engine *h, const void *d_keys_lo, const void *d_keys
 int kdf_reset_counts(kdf_engine *h) {
     if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
     HIPCHK(h, hipSetDevice(h->device));
-    int rc = materialize(h);
+    int rc = pending_drop(h);                         // counts that were never applied need not be
     if (rc) return rc;
+    if ((rc = materialize(h))) return rc;
     HIPCHK(h, hipMemsetAsync(h->t.cnt, 0, h->cap * 4, h->stream));
-    if (h->t.sk && h->t.ovf_cnt) HIPCHK(h, hipMemsetAsync(h->t.ovf_cnt, 0, (1ull << h->t.ovf_log2cap) * 4, h->stream));
     HIPCHK(h, hipMemsetAsync(h->ctl->windows, 0, sizeof(h->ctl->windows), h->stream));
     h->windows = 0;
     return KDF_OK;
@@ -1847,10 +1539,11 @@ static int add_pairs_multi(kdf_engine *h, uint32_t nseg, const uint64_t *const *
     if (total == 0) return KDF_OK;
     h->sieve_valid = false;                          // keys may join the table that the sieve has not seen
     int rc;
+    if ((rc = pending_flush(h))) return rc;
     if ((rc = ctl_sync(h, nullptr))) return rc;
     const uint32_t want = cap_log2_for(h->distinct + total);
     if (want > h->t.log2cap) {
-        if (h->lazy_empty && !h->t.sk) {             // nothing to carry over: a new table, still to be cleared
+        if (h->lazy_empty) {                         // nothing to carry over: a new table, still to be cleared
             KdfTable nt;
             if ((rc = table_alloc(h, want, nt, false))) return rc;
             HIPCHK(h, hipStreamSynchronize(h->stream));          // (nothing in flight may still touch the old arrays)
@@ -1859,16 +1552,6 @@ static int add_pairs_multi(kdf_engine *h, uint32_t nseg, const uint64_t *const *
             h->cap = 1ull << want;
         } else if ((rc = table_rehash(h, want))) return rc;
     }
-    if (h->t.sk) {
-        if ((rc = materialize(h))) return rc;
-        for (uint32_t s = 0; s < nseg; ++s) {
-            if (!n[s]) continue;
-            SkScratch sc{};
-            if ((rc = sk_insert_pairs(h, d_lo[s], d_cnt[s], n[s], 0, n[s], sc, true))) return rc;
-            if ((rc = sk_insert_finish(h, sc))) return rc;
-        }
-        return KDF_OK;
-    }
     const bool lds = counts && total >= h->opt_merge_min_pairs && nseg <= KM_MAX_SEGS && nmax < 0xFFFFFFFFull;
     if (!lds) {
         if ((rc = materialize(h))) return rc;
@@ -1876,9 +1559,9 @@ static int add_pairs_multi(kdf_engine *h, uint32_t nseg, const uint64_t *const *
             if (!n[s]) continue;
             const unsigned blocks = (unsigned)((n[s] + 255) / 256);
             if (h->kw == 1)
-                hipLaunchKernelGGL(kdf_insert_keys_kernel<1>, dim3(blocks), dim3(256), 0, h->stream, d_lo[s], (const uint64_t *)nullptr, d_cnt[s], n[s], h->t, h->ctl, 0);
+                hipLaunchKernelGGL(kdf_insert_keys_kernel<1>, dim3(blocks), dim3(256), 0, h->stream, d_lo[s], (const uint64_t *)nullptr, d_cnt[s], n[s], h->t, h->ctl, 0, 0);
             else
-                hipLaunchKernelGGL(kdf_insert_keys_kernel<2>, dim3(blocks), dim3(256), 0, h->stream, d_lo[s], d_hi[s], d_cnt[s], n[s], h->t, h->ctl, 0);
+                hipLaunchKernelGGL(kdf_insert_keys_kernel<2>, dim3(blocks), dim3(256), 0, h->stream, d_lo[s], d_hi[s], d_cnt[s], n[s], h->t, h->ctl, 0, 0);
         }
         h->last_merge_path = 2;
     } else {
@@ -1991,6 +1674,7 @@ int kdf_query_dev(kdf_engine *h, const void *d_keys_lo, const void *d_keys_hi, u
     if (n == 0) return KDF_OK;
     if (!d_keys_lo || !d_counts_out || (h->kw == 2 && !d_keys_hi)) return fail(h, KDF_ERR_INVALID, "kdf_query_dev: NULL pointer");
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcf = pending_flush(h); if (rcf) return rcf; }
     { int rc0 = materialize(h); if (rc0) return rc0; }
     const unsigned blocks = (unsigned)((n + 255) / 256);
     if (h->kw == 1)
@@ -2024,6 +1708,7 @@ int kdf_query(kdf_engine *h, const uint64_t *keys_lo, const uint64_t *keys_hi, u
 
 static int export_pass(kdf_engine *h, uint32_t min_count, bool write, uint64_t *olo, uint64_t *ohi,
                        uint32_t *ocnt, uint64_t out_cap, uint64_t *n_out) {
+    { int rcf = pending_flush(h); if (rcf) return rcf; }
     { int rc0 = materialize(h); if (rc0) return rc0; }
     HIPCHK(h, hipMemsetAsync(h->ctl->tally, 0, sizeof(h->ctl->tally) + 8, h->stream));   // tally[] + cursor
     const uint64_t waves = (h->cap + KDF_EXPORT_ROWS * 64 - 1) / (KDF_EXPORT_ROWS * 64);
@@ -2039,14 +1724,6 @@ static int export_pass(kdf_engine *h, uint32_t min_count, bool write, uint64_t *
     } else {
         hipLaunchKernelGGL((kdf_export_kernel<2, false>), dim3(blocks), dim3(256), 0, h->stream, h->t, min_count, h->ctl, olo, ohi, ocnt, out_cap);
     }
-    if (h->t.sk && h->t.ovf_lo && h->ovf_used_ub) {         // the overflow array is part of the table
-        KdfTable ov{};
-        ov.lo = h->t.ovf_lo; ov.cnt = h->t.ovf_cnt; ov.log2cap = h->t.ovf_log2cap; ov.bucket_bits = ov.log2cap;
-        const uint64_t ow = ((1ull << ov.log2cap) + KDF_EXPORT_ROWS * 64 - 1) / (KDF_EXPORT_ROWS * 64);
-        const unsigned ob = (unsigned)((ow + 3) / 4);
-        if (write) hipLaunchKernelGGL((kdf_export_kernel<1, true>), dim3(ob), dim3(256), 0, h->stream, ov, min_count, h->ctl, olo, ohi, ocnt, out_cap);   // (small array: the two-phase kernel)
-        else hipLaunchKernelGGL((kdf_export_kernel<1, false>), dim3(ob), dim3(256), 0, h->stream, ov, min_count, h->ctl, olo, ohi, ocnt, out_cap);
-    }
     HIPCHK(h, hipGetLastError());
     uint64_t cursor = 0;
     int rc = ctl_sync(h, nullptr, &cursor);
@@ -2061,8 +1738,8 @@ static int export_parts(kdf_engine *h, uint32_t min_count, uint32_t parts, bool 
                         uint64_t cap, uint64_t *part_counts_out, uint64_t *part_bytes_out, uint64_t *n_out, const char *who) {
     if (parts < 1 || parts > KDF_SHARDS) return fail(h, KDF_ERR_INVALID, "%s: parts must be 1..%d", who, KDF_SHARDS);
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcf = pending_flush(h); if (rcf) return rcf; }
     { int rc0 = materialize(h); if (rc0) return rc0; }
-    if (h->t.sk) return fail(h, KDF_ERR_STATE, "%s: the table is minimizer-bucketed (owners are not slot ranges)", who);
     if (h->t.hshift) return fail(h, KDF_ERR_STATE, "%s: an owner table (hash_shift) is not dumped by owner again", who);
     if (h->t.log2cap < 28)                                  // an owner boundary (a 16-bit hash prefix) must be a block boundary
         return fail(h, KDF_ERR_STATE, "%s: table of 2^%u slots is too small for an owner-ordered dump (needs 2^28)", who, h->t.log2cap);
@@ -2204,9 +1881,10 @@ int kdf_scan_reads_dev(kdf_engine *h, const void *d_packed, const void *d_invali
     if (n_bases == 0) return KDF_OK;
     if (!d_packed || !d_invalid || !d_hit_bits) return fail(h, KDF_ERR_INVALID, "kdf_scan_reads_dev: NULL pointer");
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcf = pending_flush(h); if (rcf) return rcf; }
     { int rc0 = materialize(h); if (rc0) return rc0; }
     const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
-    if (!h->t.sk && h->opt_force_path != 1 && n_tiles * KDF_TILE < (1ull << 32)) {
+    if (h->opt_force_path != 1 && n_tiles * KDF_TILE < (1ull << 32)) {
         // through the membership sieve (section 3.5 of DESIGN.md): an index that was loaded with kdf_add_pairs has none yet
         int rc;
         if (!h->sieve_valid) {
@@ -2333,6 +2011,8 @@ int kdf_profile_read(kdf_engine *h, double *kernel_ms, uint64_t *launches, uint6
 int kdf_set_option(kdf_engine *h, const char *name, int64_t value) {
     if (!h || !name) return fail(h, KDF_ERR_INVALID, "kdf_set_option: NULL argument");
     const std::string n(name);
+    // options change how the NEXT windows are counted: what is pending was counted under the old ones
+    if (n != "debug_flags" && n != "defer_max_bytes") { HIPCHK(h, hipSetDevice(h->device)); int rcf = pending_flush(h); if (rcf) return rcf; }
     if (n == "key_parts" || n == "key_part") {
         const uint32_t parts = n == "key_parts" ? (uint32_t)value : h->opt_key_parts, part = n == "key_part" ? (uint32_t)value : h->opt_key_part;
         if (value < 0 || parts > 65536 || (n == "key_part" && part >= std::max<uint32_t>(parts, 1)))
@@ -2350,7 +2030,6 @@ int kdf_set_option(kdf_engine *h, const char *name, int64_t value) {
     else if (n == "merge_min_pairs") h->opt_merge_min_pairs = (uint64_t)value;
     else if (n == "hash_shift") {
         if (value > 8) return fail(h, KDF_ERR_INVALID, "hash_shift must be 0..8");
-        if (h->t.sk) return fail(h, KDF_ERR_STATE, "hash_shift: the table is minimizer-bucketed");
         if ((uint32_t)value != h->opt_hash_shift) {
             int rc = ctl_sync(h, nullptr);
             if (rc) return rc;
@@ -2358,12 +2037,11 @@ int kdf_set_option(kdf_engine *h, const char *name, int64_t value) {
         }
         h->opt_hash_shift = (uint32_t)value; h->t.hshift = (uint32_t)value;
     }
-    else if (n == "sk_min_k") h->opt_sk_min_k = (uint32_t)value;
-    else if (n == "sk_balance") h->opt_sk_balance = (int)value;
-    else if (n == "sk_auto") h->opt_sk_auto = (int)value;
+    else if (n == "defer") h->opt_defer = value != 0;
+    else if (n == "defer_max_bytes") h->opt_defer_max_bytes = (uint64_t)value;
+    else if (n == "l1_positions") h->opt_l1_positions = (uint64_t)std::max<int64_t>(value, KDF_TILE);
+    else if (n == "l1_direct_positions") h->opt_l1_direct_positions = (uint64_t)std::max<int64_t>(value, 0);
     else if (n == "sieve_bits") h->opt_sieve_bits = (int)value;
-    else if (n == "binned_pool") h->opt_binned_pool = (int)value;
-    else if (n == "binned_cells") { h->opt_binned_cells = (int)value; h->cells_overflowed = false; }
     else if (n == "debug_flags") h->opt_debug_flags = (uint32_t)value;
     else return fail(h, KDF_ERR_INVALID, "kdf_set_option: unknown option %s", name);
     return KDF_OK;
@@ -2374,19 +2052,15 @@ int kdf_get_stat(kdf_engine *h, const char *name, int64_t *value) {
     const std::string n(name);
     if (n == "binned_passes") *value = (int64_t)h->stat_binned_passes;
     else if (n == "replayed_buckets") *value = (int64_t)h->stat_replayed_buckets;
-    else if (n.rfind("dbg_t", 0) == 0 && n.size() == 6 && n[5] >= '0' && n[5] <= '5') *value = (int64_t)h->stat_dbg[n[5] - '0'];
-    else if (n == "sk_passes") *value = (int64_t)h->stat_sk_passes;
-    else if (n == "sk_spills") *value = (int64_t)h->stat_sk_spills;
-    else if (n == "sk_failed_buckets") *value = (int64_t)h->stat_sk_failed;
-    else if (n == "sk_fallbacks") *value = (int64_t)h->stat_sk_fallbacks;
-    else if (n == "binned_pool") *value = h->opt_binned_pool;
-    else if (n == "binned_cells") *value = (h->opt_binned_cells && !h->cells_overflowed) ? h->opt_binned_cells : 0;
-    else if (n == "layout") *value = h->t.sk ? (h->t.sk_assign ? 2 : 1) : 0;
+    else if (n == "flushes") *value = (int64_t)h->stat_flushes;
+    else if (n == "pending_passes") *value = (int64_t)h->n_pass;
+    else if (n == "pending_positions") *value = (int64_t)(h->pend_positions + h->l1_tiles * KDF_TILE);
+    else if (n == "ring_bytes") *value = (int64_t)(h->ring_entries * 8 * h->kw);
+    else if (n == "defer") *value = h->opt_defer;
     else if (n == "last_count_path") *value = h->last_path;
     else if (n == "last_merge_path") *value = h->last_merge_path;
     else if (n == "heavy_buckets") *value = (int64_t)h->stat_heavy_buckets;
     else if (n == "hash_shift") *value = h->opt_hash_shift;
-    else if (n == "ovf_log2cap") *value = h->t.ovf_lo ? (int64_t)h->t.ovf_log2cap : 0;
     else if (n == "log2cap") *value = h->t.log2cap;
     else if (n == "bucket_bits") *value = h->t.bucket_bits;
     else return fail(h, KDF_ERR_INVALID, "kdf_get_stat: unknown stat %s", name);

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(KM_THREADS) void km_write_kernel(KdfTable t, uint32
     for (uint32_t r = 0; r < KM_SPT; ++r) {
         sub[r] = 0xFFFFFFFFu;
         if (km_keep<KW>(lo[r], hi[r], c[r], min_count)) {
-            const uint64_t h = kdf_hash(lo[r], hi[r]) << t.hshift;
+            const uint64_t h = lo[r] << t.hshift;                   // the slot holds the hash (stored form)
             sub[r] = (uint32_t)((h << pre_bits) >> (64 - KM_SUB_BITS));
             rank[r] = atomicAdd(&hist[sub[r]], 1u);
         }
@@ -158,11 +158,11 @@ __global__ __launch_bounds__(KM_THREADS) void km_write_kernel(KdfTable t, uint32
             const uint64_t pos = base + start[sub[r]] + rank[r];
             if constexpr (PACKED) {
                 const uint64_t i = pos - p_first;
-                ((uint64_t *)seg)[i] = lo[r];
+                ((uint64_t *)seg)[i] = kdf_key_lo(lo[r], KW == 2 ? hi[r] : 0);      // keys leave the engine as keys
                 if (KW == 2) ((uint64_t *)seg)[p_n + i] = hi[r];
                 ((uint32_t *)(seg + p_n * 8ull * KW))[i] = c[r];
             } else if (pos < out_cap) {
-                olo[pos] = lo[r];
+                olo[pos] = kdf_key_lo(lo[r], KW == 2 ? hi[r] : 0);
                 if (KW == 2 && ohi) ohi[pos] = hi[r];
                 if (ocnt) ocnt[pos] = c[r];
             }
@@ -315,11 +315,13 @@ __global__ __launch_bounds__(KM_THREADS) void km_merge_kernel(KdfTable t, KmSegs
             bool todo = i < e;
             uint64_t lo = KDF_EMPTY, hi = 0; uint32_t add = 0;
             if (todo) { lo = klo[i]; if (KW == 2) hi = khi[i]; add = kc ? kc[i] : 0u; }
-            const uint32_t sl = (uint32_t)kdf_home(t, kdf_hash(lo, hi)) & bmask;
+            const bool absent = KW == 1 ? lo == KDF_EMPTY : hi == KDF_EMPTY;     // (tested on the key as it arrived)
+            lo = kdf_hash(lo, KW == 2 ? hi & ~KDF_PENDING : 0);                  // the table holds stored forms
+            const uint32_t sl = (uint32_t)kdf_home(t, lo) & bmask;
             if (KW == 1) {
-                if (todo && lo != KDF_EMPTY) km_probe_narrow(tlo, tcnt, bmask, lo, add, sl, claimed, failed);
+                if (todo && !absent) km_probe_narrow(tlo, tcnt, bmask, lo, add, sl, claimed, failed);
             } else {
-                todo = todo && hi != KDF_EMPTY;
+                todo = todo && !absent;
                 while (__any(todo)) {
                     if (todo) {
                         const int res = km_probe_wide_once(tlo, thi, tcnt, bmask, lo, hi & ~KDF_PENDING, add, sl, claimed);
@@ -358,11 +360,12 @@ __global__ __launch_bounds__(256) void km_insert_guarded_kernel(KdfTable t, KmSe
         const uint64_t lo = i < n ? sg.lo[seg][i] : KDF_EMPTY, hi = (KW == 2 && i < n) ? sg.hi[seg][i] : (KW == 2 ? KDF_EMPTY : 0);
         const bool todo = i < n && (KW == 1 ? lo != KDF_EMPTY : hi != KDF_EMPTY);
         const uint32_t a = (todo && sg.cnt[seg]) ? sg.cnt[seg][i] : 0u;
-        const uint64_t slot = kdf_home(t, kdf_hash(lo, hi));
+        const uint64_t h = kdf_hash(lo, KW == 2 ? hi & ~KDF_PENDING : 0);
+        const uint64_t slot = kdf_home(t, h);
         if constexpr (KW == 1) {
-            if (todo && !kdf_add_narrow<true>(t, lo, a, slot, t.lo[slot], claimed)) full = true;
+            if (todo && !kdf_add_narrow<true>(t, h, a, slot, t.lo[slot], claimed)) full = true;
         } else {
-            if (!kdf_add_wide<true>(t, todo, lo, hi & ~KDF_PENDING, a, slot, claimed)) full = true;
+            if (!kdf_add_wide<true>(t, todo, h, hi & ~KDF_PENDING, a, slot, claimed)) full = true;
         }
     }
     if (full) atomicOr(&ctl->error, 1u);

@@ -16,22 +16,36 @@ from typing import Dict, Optional, Tuple
 
 import numpy as np
 
-_registry: Dict[str, Tuple[object, Optional[object], int]] = {}
+_registry: Dict[str, Tuple[object, Optional[object], int, Tuple[int, int]]] = {}
 
 
 def _key(path: str) -> str:
     return os.path.abspath(path)
 
 
+def _stamp(path: str):
+    st = os.stat(path)
+    return (st.st_size, st.st_mtime_ns)
+
+
 def register(path: str, lo, hi, k: int):
-    """``lo`` / ``hi``: int64 CUDA tensors (bit patterns of the uint64 key words); hi None for k <= 32."""
-    _registry[_key(path)] = (lo, hi, int(k))
+    """``lo`` / ``hi``: int64 CUDA tensors (bit patterns of the uint64 key words); hi None for k <= 32.
+    Call right after the FASTA at ``path`` was written: its size and mtime are the set's identity."""
+    _registry[_key(path)] = (lo, hi, int(k), _stamp(path))
 
 
 def lookup(path: str, k: int):
-    """(lo, hi) device tensors registered for ``path`` at this k, or None."""
+    """(lo, hi) device tensors registered for ``path`` at this k, or None.  A file that was rewritten since
+    (a resumed run, an edited FASTA, a second trio in the same tmpdir) no longer matches and is parsed instead."""
     ent = _registry.get(_key(path))
-    if ent is None or ent[2] != int(k) or not os.path.exists(path):
+    if ent is None:
+        return None
+    try:
+        same = ent[2] == int(k) and _stamp(path) == ent[3]
+    except OSError:
+        same = False
+    if not same:
+        _registry.pop(_key(path), None)
         return None
     return ent[0], ent[1]
 
@@ -56,15 +70,19 @@ def from_host(lo: np.ndarray, hi: Optional[np.ndarray], wide: bool, device: int 
 
 
 def dump_ge(eng, min_count: int, device: int = 0):
-    """``jellyfish dump -c -L min_count`` into device tensors (unsorted: the reference does not rely on the order)."""
+    """``jellyfish dump -c -L min_count`` into device tensors, ascending key order (the reference does not rely on
+    the order, but a sorted dump makes the contract FASTA files byte-reproducible from run to run)."""
     import torch
     dev = torch.device("cuda", device)
     n = eng.count_ge(min_count)
     lo = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
     hi = torch.empty(max(n, 1), dtype=torch.int64, device=dev) if eng.wide else None
+    cnt = torch.empty(max(n, 1), dtype=torch.int32, device=dev)      # (the device sort carries the counts along)
     torch.cuda.current_stream(dev).synchronize()
-    got = eng.export_ge_dev(min_count, lo.data_ptr(), hi.data_ptr() if hi is not None else None, None, n) if n else 0
-    assert got == n
+    got = eng.export_ge_dev(min_count, lo.data_ptr(), hi.data_ptr() if hi is not None else None, cnt.data_ptr(), n,
+                            sorted_=True) if n else 0
+    if got != n:
+        raise RuntimeError(f"dump -L {min_count}: {got} entries written, {n} counted")
     return lo[:n], (hi[:n] if hi is not None else None)
 
 

@@ -80,8 +80,8 @@ def _extract_child_kmers_discovery(child_bam, ref_fasta, kmer_size, min_child_co
                             _format_elapsed(time.monotonic() - extract_start), part + 1, parts, windows, distinct, cap)
                 logger.info("Dumping child k-mers with count >= %d…", min_child_count)
                 dump_start = time.monotonic()
-                # the dump stays in HBM for the next stage (unsorted: Jellyfish's dump order is not reproducible
-                # either and nothing downstream relies on it); the FASTA below is the file contract
+                # the dump stays in HBM for the next stage (ascending keys: Jellyfish's dump order is not reproducible and
+                # nothing downstream relies on it, but the contract files are then the same bytes on every run)
                 dlo, dhi = devkeys.dump_ge(eng, min_child_count, eng.device)
                 dev_sets.append((dlo, dhi))
                 lo, hi = devkeys.to_host(dlo, dhi)
@@ -207,6 +207,7 @@ def _filter_parents_discovery(mother_bam, father_bam, ref_fasta, child_non_ref_f
     except (KdfError, ValueError, OSError) as e:
         raise RuntimeError(f"jellyfish count (Mother) failed: {e}") from e
     dlo, dhi = dev
+    devkeys.forget(child_non_ref_fa)                             # taken: the registry must not pin GBs of HBM for the life of the process
     n_input = int(dlo.numel())
     if n_input == 0:
         return 0, None
@@ -235,7 +236,6 @@ def _filter_parents_discovery(mother_bam, father_bam, ref_fasta, child_non_ref_f
     dlo, dhi = one_parent(father_bam, "Father", dlo, dhi)
     proband_unique_fa = os.path.join(tmpdir, "proband_unique.fa")
     n_proband = write_kmer_fasta(proband_unique_fa, *devkeys.to_host(dlo, dhi), kmer_size)
-    devkeys.register(proband_unique_fa, dlo, dhi, kmer_size)
     remove_with_sidecar(after_mother_fa)
     logger.info("Father: %d / %d surviving k-mers found (count > %d), %d proband-unique",
                 n_surviving - n_proband, n_surviving, parent_max_count, n_proband)

@@ -52,7 +52,7 @@ def owner_of(lo: torch.Tensor, hi: Optional[torch.Tensor], world: int) -> torch.
     x = lo
     if hi is not None:
         x = lo ^ ((hi << 37) | _lsr(hi, 27))
-    h = (x ^ _lsr(x, 32)) * -0x61C8864680B583EB           # 0x9E3779B97F4A7C15 as int64
+    h = (x ^ _lsr(x, 32)) * -0x604DE39AE16720DB           # KDF_MIX_MUL = 0x9FB21C651E98DF25 as int64
     return (_lsr(h, 48) * world) >> 16
 
 
@@ -118,7 +118,7 @@ class EngineOps(TableOps):
     def export_pairs_by_owner(self, world: int):
         """(lo, hi, cnt, per-owner counts) already grouped by owner rank, or None when
         the table is too small for the engine's owner-ordered dump."""
-        if self.e.get_stat("layout") != 0 or self.e.get_stat("log2cap") < 28 or world > 64 or self.e.get_stat("hash_shift"):
+        if self.e.get_stat("log2cap") < 28 or world > 64 or self.e.get_stat("hash_shift"):
             return None
         _, distinct, _ = self.e.stats()
         lo = torch.empty(distinct, dtype=torch.int64, device=self.device)
@@ -134,7 +134,7 @@ class EngineOps(TableOps):
         """(send buffer uint8, per-owner pair counts, per-owner byte offsets [world + 1]): the owner-ordered dump written
         by the engine straight into the layout `OwnerPartitionedCount.exchange` sends -- no (lo, hi, cnt) temporaries, no
         packing copies.  None when the table cannot be dumped by owner (see export_pairs_by_owner)."""
-        if self.e.get_stat("layout") != 0 or self.e.get_stat("log2cap") < 28 or world > 64 or self.e.get_stat("hash_shift"):
+        if self.e.get_stat("log2cap") < 28 or world > 64 or self.e.get_stat("hash_shift"):
             return None
         _, distinct, _ = self.e.stats()
         cap = distinct * (20 if self.wide else 12) + 8 * world + 8
@@ -210,9 +210,10 @@ class ShardedFilterCount:
 
         The counts travel as ONE all-reduce(sum) of 4-byte words (the `ncclUint32` reduce of
         SURVEY.md section 8e): a scalar all-reduce(max) of the largest local count first
-        proves that world x max < 2^32, i.e. that the 32-bit sums cannot wrap.  Only when
-        that fails (counts near Jellyfish's 4-byte ceiling) the sum is taken in 8-byte words
-        and clamped."""
+        proves that world x max < 2^31, i.e. that the sums stay inside the SIGNED 32-bit range
+        the backends reduce in (a sum in [2^31, 2^32) would be signed overflow inside gloo's /
+        RCCL's `+`).  Only when that fails (counts within a factor `world` of 2^31) the sum is
+        taken in 8-byte words and clamped."""
         local32 = self.ops.query(keys_lo, keys_hi)                 # int32 bit patterns of uint32 counts
         if self.world == 1 or local32.numel() == 0:
             return _u32(local32)
@@ -220,8 +221,8 @@ class ShardedFilterCount:
             local32 = local32.cpu()
         mx = _u32(local32).max().reshape(1)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
-        if int(mx.item()) * self.world <= _U32_MAX:
-            dist.all_reduce(local32, op=dist.ReduceOp.SUM, group=self.group)   # wraps like uint32: proven not to
+        if int(mx.item()) * self.world <= 0x7FFFFFFF:
+            dist.all_reduce(local32, op=dist.ReduceOp.SUM, group=self.group)   # proven to stay below 2^31
             self.last_reduce_dtype = torch.int32
             out = _u32(local32)
         else:
@@ -266,7 +267,9 @@ class OwnerPartitionedCount:
         self.last_exchange_pairs = 0
 
     def local_stats(self):
-        return self._local_stats
+        """(capacity, distinct, windows) of this rank's LOCAL table.  Reading them applies what the count calls have
+        deferred: ask after the last batch, not after every batch."""
+        return self.local.stats()
 
     def exchange(self):
         """Move every locally counted (key, count) pair to its owner rank: one count exchange and ONE
@@ -349,7 +352,6 @@ class OwnerPartitionedCount:
         if isinstance(packed, int):
             raise TypeError("pass the stream tensors, not raw pointers")
         self.local.count_stream(packed, invalid, n_bases)
-        self._local_stats = self.local.stats()
 
     def merge(self, min_count: int = 1) -> int:
         """Exchange the local (key, count) pairs to their owners; returns the global

@@ -71,6 +71,11 @@ class KmerEngine:
     def synchronize(self):
         self._ck(self._lib.kdf_synchronize(self._h))
 
+    def flush(self):
+        """Apply everything the count calls have deferred (pending stream, partitioned passes) to the table now."""
+        self._ck(self._lib.kdf_flush(self._h))
+        return self
+
     def clear(self):
         self._ck(self._lib.kdf_clear(self._h))
 
@@ -110,23 +115,15 @@ class KmerEngine:
         self._ck(self._lib.kdf_profile_stages(self._h, ms, byref(n)))
         return list(ms), n.value
 
-    _PATHS = ("direct", "binned", "superkmer", "sieve")
-    _STAGES = {
-        "binned": ["kb_hist1_kernel(+scans)", "kb_scatter1_kernel", "kb_finesort_kernel", "kb_bucket_kernel"],
-        "superkmer": ["sk_extract_kernel", "sk_binscan+sk_chunklist", "sk_finesort_kernel", "sk_bucket_kernel"],
-    }
+    _PATHS = ("direct", "binned", "-", "sieve")
+    _STAGES = ["kb_hist1_kernel(+scans)", "kb_scatter1_kernel", "kb_finesort_kernel", "kb_bucket_kernel"]
 
     def last_count_path(self) -> str:
-        """Which pipeline the last count call took: direct / binned / superkmer."""
+        """Which pipeline the last count call took: direct / binned / sieve."""
         return self._PATHS[self.get_stat("last_count_path")]
 
     def profile_stage_names(self):
-        path = self.last_count_path()
-        if path == "binned" and self.get_stat("binned_cells") and not self.get_stat("binned_pool"):
-            return ["kb_scatter1_kernel<cells>", "-", "kb_finesort_kernel<cells>", "kb_bucket_kernel"]
-        if path == "binned" and self.get_stat("binned_pool"):
-            return ["kb_scatter2_kernel", "kb_poolscan+kb_chunklist", "kb_finesort2_kernel", "kb_bucket_kernel"]
-        return self._STAGES.get(path, self._STAGES["binned"])
+        return list(self._STAGES)
 
     # -- count / filter ----------------------------------------------------
     def count(self, stream: ReadStream):

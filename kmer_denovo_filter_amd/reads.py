@@ -333,7 +333,7 @@ def stream_batches_overlapped(engine, reader, filtered: bool, ring: int = 3) -> 
                 n_reads += st.n_reads
                 if pending is not None:
                     engine.count_uploaded(pending[0], filtered)
-                    free.put(pending[1])                 # its copy finished before its count started
+                    free.put(pending[1])                 # count_uploaded waited (on the HOST) for this buffer's copy
                 pending = (slot, i)
                 slot ^= 1
             if pending is not None:
@@ -342,7 +342,7 @@ def stream_batches_overlapped(engine, reader, filtered: bool, ring: int = 3) -> 
         finally:
             stop.set()
             free.put(None)
-            th.join(timeout=60)
+            th.join()                                    # the native reader call always returns; never close the reader under it
             engine.synchronize()                         # no copy may still read a pinned buffer the next caller will fill
     return n_reads
 

@@ -139,6 +139,13 @@ def _worker(rank, world, port, k, q):
         sb = ShardedFilterCount(big)
         mb = sb.merged_counts(torch.zeros(3, dtype=torch.int64), None)
         assert sb.last_reduce_dtype == torch.int64 and mb.tolist() == [0xFFFFFFFF, 5 * world, 0]
+        # per-rank counts whose SUM lands in [2^31, 2^32): no uint32 wrap, but signed overflow in a 4-byte reduction --
+        # must travel as 8-byte words too, and come out exact
+        per = (0x80000000 + 1000) // world + 1
+        mid = _FixedCounts(torch.tensor([per, 7, 0], dtype=torch.int32))
+        sm = ShardedFilterCount(mid)
+        mm = sm.merged_counts(torch.zeros(3, dtype=torch.int64), None)
+        assert sm.last_reduce_dtype == torch.int64 and mm.tolist() == [per * world, 7 * world, 0] and per * world >= 2**31
         # a rank-local owner table is mandatory with more than one rank (the default used to double count)
         try:
             OwnerPartitionedCount(OracleOps(O, k))

@@ -55,7 +55,7 @@ def khash(lo, hi):
     if hi is not None:
         x ^= (hi << np.uint64(37)) | (hi >> np.uint64(27))
     with np.errstate(over="ignore"):
-        return (x ^ (x >> np.uint64(32))) * np.uint64(0x9E3779B97F4A7C15)
+        return (x ^ (x >> np.uint64(32))) * np.uint64(0x9FB21C651E98DF25)
 
 
 def round2_case(O, rng, scale, tag0):
@@ -69,29 +69,37 @@ def round2_case(O, rng, scale, tag0):
     if rng.random() < 0.3:
         reads += ["A" * int(rng.integers(k, 500))] * int(rng.integers(1, 60)) + ["ACGT" * 100] * int(rng.integers(0, 20))
     wide = k > 32
-    paths = [1, 2] + ([3, 3] if 16 <= k <= 32 else [])
+    paths = [0, 1, 2, 2]
     path = int(rng.choice(paths))
-    cells = int(rng.choice([0, 2])) if path == 2 else 0
-    pool = int(rng.choice([0, 1])) if path == 2 and not cells else 0
+    defer = int(rng.choice([0, 1, 1]))                       # kernel C deferred over the batches, or a flush per count call
+    l1 = int(rng.choice([1 << 12, 1 << 16, 1 << 30]))        # (auto path) pending-stream size that triggers a partition
     hshift = int(rng.choice([0, 0, 1, 3]))
     hint = int(rng.choice([1 << 8, 1 << 12, 1 << 16, 1 << 20]))
     maxpos = int(rng.choice([1 << 31, 4096, 65536]))
-    tag = f"{tag0} k={k} reads={len(reads)} path={path} cells={cells} pool={pool} hshift={hshift} hint={hint} maxpos={maxpos}"
+    tag = f"{tag0} k={k} reads={len(reads)} path={path} defer={defer} l1={l1} hshift={hshift} hint={hint} maxpos={maxpos}"
     lo, hi, cnt = O.OracleTable(k, 1 << 12).count_reads(reads).export_ge(0)
 
     skewvar = 4096 if rng.random() < 0.5 else 0              # kernel C's skew instantiation (wave-aggregated count adds), forced
 
     def opts(e, p=path):
         e.set_option("force_path", p); e.set_option("binned_max_positions", maxpos); e.set_option("debug_flags", skewvar)
-        e.set_option("binned_cells", cells); e.set_option("binned_pool", pool)
+        e.set_option("defer", defer); e.set_option("l1_positions", l1); e.set_option("l1_direct_positions", 4 * l1)
+        e.set_option("binned_min_positions", int(rng.choice([1 << 10, 1 << 22])))
 
     with KmerEngine(k, capacity_hint=hint) as e:
         opts(e)
         if hshift:
             e.set_option("hash_shift", hshift)
         half = len(reads) // 2
-        if rng.random() < 0.5:
+        r = rng.random()
+        if r < 0.35:
             e.count(ReadStream.from_strings(reads[:half])); e.count(ReadStream.from_strings(reads[half:]))
+        elif r < 0.7:                                        # a streamed sample: many small batches, something read in between
+            step = max(1, len(reads) // int(rng.integers(3, 12)))
+            for a in range(0, len(reads), step):
+                e.count(ReadStream.from_strings(reads[a:a + step]))
+                if rng.random() < 0.2:
+                    e.count_ge(1)
         else:
             e.count(ReadStream.from_strings(reads))
         glo, ghi, gcnt = e.export_ge(0)
@@ -164,8 +172,8 @@ def round2_case(O, rng, scale, tag0):
 
 @pytest.mark.parametrize("seed", [404, 505])
 def test_random_cases_round2_paths(oracle, seed):
-    """The round-2 paths (scratch/fuzz_round2.py ran 5 849 such cases on the GPU box without a difference): super-k-mer
-    pipeline, cell / pool scatter, owner tables (hash_shift), the multi-segment merge in hash order (LDS buckets) and out
+    """The round-2 / round-3 paths (scratch/fuzz_round2.py): deferred kernel C over streamed batches, the pending stream
+    of small batches, owner tables (hash_shift), the multi-segment merge in hash order (LDS buckets) and out
     of order (atomic fallback), into fresh, cleared and live tables, and count --if through the sieve at every width."""
     rng = np.random.default_rng(seed)
     taken = set()

@@ -26,7 +26,7 @@ def _hash(lo, hi):
     if hi is not None:
         x ^= (hi << np.uint64(37)) | (hi >> np.uint64(27))
     with np.errstate(over="ignore"):
-        return (x ^ (x >> np.uint64(32))) * np.uint64(0x9E3779B97F4A7C15)
+        return (x ^ (x >> np.uint64(32))) * np.uint64(0x9FB21C651E98DF25)
 
 
 def _dump_parts(e, world):

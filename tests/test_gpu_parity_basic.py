@@ -257,7 +257,7 @@ def test_count_in_key_space_slices(oracle, k, path):
     def slice_of(lo_, hi_, parts):                         # kdf_slice(kdf_hash(lo, hi), parts) of csrc/kdf_device.h
         M = (1 << 64) - 1
         x = lo_ ^ (((hi_ << 37) | (hi_ >> 27)) & M)
-        h = ((x ^ (x >> 32)) * 0x9E3779B97F4A7C15) & M
+        h = ((x ^ (x >> 32)) * 0x9FB21C651E98DF25) & M
         return ((h & 0xFFFF) * parts) >> 16
     rng = np.random.default_rng(21)
     genome = rng.integers(0, 4, 60_000).astype(np.uint8)
@@ -335,57 +335,77 @@ def test_count_filtered_through_the_sieve(oracle, k):
 
 
 @pytest.mark.parametrize("k", [31, 47])
-def test_binned_pool_variant_matches_oracle(oracle, k):
-    """Option binned_pool = 1: the scatter without a histogram pass (runs go to 4 KB chunks taken from a pool, the
-    fine sort works on groups of chunks).  Not the default (it measured slower), but it must stay exact."""
+def test_deferred_flush_equals_eager_equals_direct(oracle, k):
+    """A sample streamed in many batches (discovery/pipeline.py:106-172: ONE `jellyfish count` over the whole
+    `samtools fasta` pipe).  Kernel C deferred over the pending partition passes == a flush after every count call ==
+    the direct global-atomic path == the oracle, with `query` / `count_ge` issued in the middle of the stream (they see
+    exactly the batches counted so far), a table that is far too small (it grows, buckets are replayed) and a heavy
+    homopolymer batch (the skew instantiation of kernel C and its heavy-bucket split)."""
     from kmer_denovo_filter_amd import KmerEngine, ReadStream
     rng = np.random.default_rng(1300 + k)
     genome = rng.integers(0, 4, 60000).astype(np.uint8)
-    reads = rand_reads(rng, 3000, 0, 300, genome=genome) + ["", "A" * 500, "N" * 70, "ACGT" * 80]
+    reads = rand_reads(rng, 4000, 0, 300, genome=genome) + ["", "A" * 500, "N" * 70, "ACGT" * 80] + ["A" * 300] * 3000
+    batches = [reads[i::8] for i in range(8)]
     t, (lo, hi, cnt) = oracle_sorted(oracle, k, reads)
-    with KmerEngine(k, capacity_hint=1 << 13) as e:
-        e.set_option("force_path", 2); e.set_option("binned_pool", 1)
-        half = len(reads) // 2
-        e.count(ReadStream.from_strings(reads[:half])); e.count(ReadStream.from_strings(reads[half:]))
-        glo, ghi, gcnt = e.export_ge(0)
-        assert e.stats()[2] == oracle.count_windows(reads, k) and e.get_stat("replayed_buckets") > 0
-        np.testing.assert_array_equal(glo, lo); np.testing.assert_array_equal(ghi, hi); np.testing.assert_array_equal(gcnt, cnt)
+    part = [b for bt in batches[:3] for b in bt]
+    tp, (plo, phi, pcnt) = oracle_sorted(oracle, k, part)
+    dumps = {}
+    for name, path, defer, hint in (("deferred", 2, 1, 1 << 13), ("eager", 2, 0, 1 << 13), ("direct", 1, 1, 1 << 13),
+                                    ("deferred-big", 2, 1, 1 << 20)):
+        with KmerEngine(k, capacity_hint=hint) as e:
+            e.set_option("force_path", path); e.set_option("defer", defer)
+            for i, bt in enumerate(batches):
+                e.count(ReadStream.from_strings(bt))
+                if i == 2:                                        # mid-stream reads of the table: everything counted so far, nothing else
+                    if path == 2 and defer:
+                        assert e.get_stat("pending_passes") == 3 and e.get_stat("flushes") == 0
+                    assert e.count_ge(2) == int((pcnt >= 2).sum())
+                    np.testing.assert_array_equal(e.query(plo[::7], phi[::7] if k > 32 else None), pcnt[::7])
+                    assert e.get_stat("pending_passes") == 0
+            glo, ghi, gcnt = e.export_ge(0)
+            if path == 2:
+                assert e.get_stat("binned_passes") == 8
+                assert e.get_stat("flushes") == (2 if defer else 8)
+            assert e.stats()[2] == oracle.count_windows(reads, k)
+            if name == "deferred":
+                assert e.get_stat("replayed_buckets") > 0         # the table started far too small
+            np.testing.assert_array_equal(glo, lo); np.testing.assert_array_equal(ghi, hi); np.testing.assert_array_equal(gcnt, cnt)
+            dumps[name] = (glo, gcnt)
 
 
-@pytest.mark.parametrize("k", [31, 47])
-def test_binned_cells_variant_and_its_overflow_fallback(oracle, k):
-    """The default binned pass of big batches has no histogram pass: every (bin, workgroup) pair scatters into a fixed
-    cell (option binned_cells; 2 = at any batch size, for this test).  Skewed input overflows a cell: the later stages
-    then do nothing and the pass is redone with the exact layout -- same result, and the engine stays on the exact path."""
+@pytest.mark.parametrize("k", [27, 63])
+def test_pending_stream_of_small_batches(oracle, k):
+    """Auto path: small batches are concatenated in the pending stream (every batch starts on a tile boundary; the bits
+    past a batch's end read invalid whatever the source holds), partitioned when the stream reaches `l1_positions`,
+    bigger batches are partitioned where they lie; `kdf_clear` drops what is pending; a flush of little goes direct."""
     from kmer_denovo_filter_amd import KmerEngine, ReadStream
     rng = np.random.default_rng(1700 + k)
-    genome = rng.integers(0, 4, 60000).astype(np.uint8)
-    reads = rand_reads(rng, 3000, 0, 300, genome=genome) + ["", "N" * 70, "ACGT" * 80]
+    genome = rng.integers(0, 4, 80000).astype(np.uint8)
+    reads = rand_reads(rng, 6000, 0, 300, genome=genome) + ["", "N" * 70, "ACGT" * 80]
     t, (lo, hi, cnt) = oracle_sorted(oracle, k, reads)
-    with KmerEngine(k, capacity_hint=1 << 20) as e:               # (a table with few buckets has few bins: no cells then)
-        e.set_option("force_path", 2); e.set_option("binned_cells", 2)
-        half = len(reads) // 2
-        e.count(ReadStream.from_strings(reads[:half])); e.count(ReadStream.from_strings(reads[half:]))
-        assert e.get_stat("binned_cells") == 2 and e.get_stat("binned_passes") == 2
+    sizes = [1, 7, 300, 64, 1500, 2, 900, 33]                     # reads per batch, cycled: ragged batches
+    with KmerEngine(k, capacity_hint=1 << 18) as e:
+        e.set_option("l1_positions", 150_000); e.set_option("l1_direct_positions", 400_000); e.set_option("binned_min_positions", 10_000)
+        e.set_option("binned_bytes_per_position", 1 << 20)
+        e.count(ReadStream.from_strings(reads[:50]))              # ... and dropped:
+        e.clear()
+        assert e.stats()[1:] == (0, 0)
+        a, i = 0, 0
+        while a < len(reads):
+            n = sizes[i % len(sizes)]; i += 1
+            e.count(ReadStream.from_strings(reads[a:a + n])); a += n
+        assert e.get_stat("binned_passes") >= 2                   # the pending stream filled up more than once
         glo, ghi, gcnt = e.export_ge(0)
         assert e.stats()[2] == oracle.count_windows(reads, k)
         np.testing.assert_array_equal(glo, lo); np.testing.assert_array_equal(ghi, hi); np.testing.assert_array_equal(gcnt, cnt)
-    # 4.8 M positions of one repeated read: every workgroup takes two slabs (more slabs than CUs) whose 32 K equal
-    # windows fall into ONE bin -- twice what a cell holds
-    heavy = reads[:500] + ["A" * 300] * 16000
-    t2, (lo2, hi2, cnt2) = oracle_sorted(oracle, k, heavy)
-    with KmerEngine(k, capacity_hint=1 << 22) as e:
-        e.set_option("force_path", 2); e.set_option("binned_cells", 2)
-        e.count(ReadStream.from_strings(heavy))
-        assert e.get_stat("binned_cells") == 0                    # fell back, and stays there
+        # little pending at flush time: the direct kernels
+        e.set_option("binned_min_positions", 1 << 22)
+        e.count(ReadStream.from_strings(reads[:40]))
+        t2 = oracle.OracleTable(k, 1 << 12).count_reads(reads).count_reads(reads[:40])
+        lo2, hi2, cnt2 = t2.export_ge(0)
         glo, ghi, gcnt = e.export_ge(0)
-        assert e.stats()[2] == oracle.count_windows(heavy, k)
+        assert e.last_count_path() == "direct"
         np.testing.assert_array_equal(glo, lo2); np.testing.assert_array_equal(gcnt, cnt2)
-        e.count(ReadStream.from_strings(reads[:300]))
-        t3 = oracle.OracleTable(k, 1 << 12).count_reads(heavy).count_reads(reads[:300])
-        l3, h3, c3 = t3.export_ge(0)
-        glo, ghi, gcnt = e.export_ge(0)
-        np.testing.assert_array_equal(glo, l3); np.testing.assert_array_equal(gcnt, c3)
 
 
 def test_heavy_buckets_are_split_and_stay_exact(oracle):

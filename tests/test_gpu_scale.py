@@ -223,26 +223,31 @@ def test_owner_partitioned_count_two_processes(k):
 
 
 def test_path_choice_follows_batch_and_table_size():
-    """A binned pass rewrites every bucket of the table whatever the batch holds, so a small batch into a big table takes
-    the direct kernels and a big batch the binned pipeline (csrc/kdf_engine.hip use_binned: ~14 M positions per GB); the
-    tables they build are the same."""
+    """Kernel C rewrites every bucket of the table whatever the pending passes hold, so a FLUSH of little into a big table
+    takes the direct kernels and a flush of much the binned pipeline (csrc/kdf_engine.hip use_binned: ~14 M positions per
+    GB); without flushes in between the small batches ride along with the big one; the tables are the same."""
     import torch
     from kmer_denovo_filter_amd import KmerEngine
     small, big = _dev_stream(100_000, seed=1), _dev_stream(2_000_000, seed=2)        # 15 M / 302 M positions
     dumps = {}
-    for name, force in (("auto", 0), ("direct", 1), ("binned", 2)):
+    for name, force in (("auto", 0), ("auto-deferred", 0), ("direct", 1), ("binned", 2)):
         with KmerEngine(31, capacity_hint=1 << 27) as e:                          # 2^28 slots = 3.2 GB: crossover ~46 M positions
             e.set_option("force_path", force)
             taken = []
             for ds in (small, big, small):
-                e.count_dev(ds.packed.data_ptr(), ds.invalid.data_ptr(), ds.n_bases); e.synchronize()
+                e.count_dev(ds.packed.data_ptr(), ds.invalid.data_ptr(), ds.n_bases)
+                if name != "auto-deferred":
+                    e.flush()
                 taken.append(e.last_count_path())
             if name == "auto":
                 assert taken == ["direct", "binned", "direct"], taken
+            if name == "auto-deferred":
+                e.flush()
+                assert e.get_stat("flushes") == 1 and e.get_stat("binned_passes") == 2 and e.last_count_path() == "binned"
             _, distinct, windows = e.stats()
             lo = torch.empty(distinct, dtype=torch.int64, device="cuda:0"); cnt = torch.empty(distinct, dtype=torch.int32, device="cuda:0")
             n = e.export_ge_dev(0, lo.data_ptr(), None, cnt.data_ptr(), distinct, sorted_=True); e.synchronize()
             dumps[name] = (lo[:n], cnt[:n], windows)
-    for name in ("direct", "binned"):
+    for name in ("direct", "binned", "auto-deferred"):
         assert dumps[name][2] == dumps["auto"][2]
         assert torch.equal(dumps[name][0], dumps["auto"][0]) and torch.equal(dumps[name][1], dumps["auto"][1])
