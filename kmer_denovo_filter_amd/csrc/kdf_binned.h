@@ -3,21 +3,26 @@
 // The table (kdf_device.h) is an array of buckets of 2^bucket_bits slots; a
 // key's bucket is the top bits of its hash.  Random probes into an HBM table
 // move a 64-128 B sector per 8 useful bytes and pay a device atomic per window.
-// Instead, a batch of reads is PARTITIONED
+// Instead, a batch of reads is PARTITIONED, reading the stream ONCE:
 //
-//   A0  histogram of the coarse bin (top c1 hash bits) of every valid window
-//   A1  extract canonical k-mers again and scatter their STORED FORM h (kdf_device.h: the hash is a bijection,
-//       so the entry IS the hash and no later stage evaluates it again) to their coarse bin:
-//       LDS counting sort per slab -> coalesced run writes
-//   B   every CHUNK-entry chunk of a coarse bin is sorted IN PLACE by the next
-//       c2 hash bits; a per-chunk offset table locates each fine run
-//       (no global fine histogram, immune to multiplicity skew)
+//   A   kb_slabsort_kernel: every slab of SLAB stream positions is turned into the STORED FORMS h of its canonical
+//       k-mers (kdf_device.h: the hash is a bijection, so the entry IS the hash and no later stage evaluates it
+//       again), counting-sorted in LDS by coarse bin (top c1 hash bits) and written out as ONE contiguous block,
+//       with the slab's bin offsets (a row of u16).  No histogram pass, no global cursors, no partial cache lines.
+//   P   kb_groupsum_kernel / kb_plan_kernel: G consecutive slabs form a GROUP; the entries of bin c in group g are a
+//       PIECE of ~0.93 CHUNK entries (more under skew: then several pieces).  Exact piece sizes from the offset rows
+//       (190 MB for 1.5 G positions), piece -> row of the offset table, compact piece -> ring position, per-bin piece lists.
+//   B   kb_piecesort_kernel: one workgroup per piece gathers its runs (one per slab of the group), sorts them in LDS
+//       by the next c2 hash bits and appends the sorted piece + its offset row to the engine's entry RING.
 //
-// into the engine's entry RING, pass after pass (a streamed sample is many batches into one table), and the ring is
-// APPLIED to the table only when something needs the table (dump / query / stats ...) or the ring is full:
+// Rounds 1-2 read the stream twice (a histogram pass A0 fixed an exact place for every (workgroup, bin) run before the
+// scatter A1 could copy its runs out bin by bin); A0 + A1 took 5.9 ms of a 14.3 ms pass.
 //
-//   C   one workgroup per table bucket: bucket slice (keys+counts) lives in
-//       LDS, the bucket's runs are gathered from all chunks of its coarse bin IN EVERY PENDING PASS
+// Pass after pass is appended to the ring (a streamed sample is many batches into one table); the ring is APPLIED to the
+// table only when something needs the table (dump / query / stats ...) or the ring is full:
+//
+//   C   kb_bucket_kernel: one workgroup per table bucket: bucket slice (keys+counts) lives in
+//       LDS, the bucket's runs are gathered from all pieces of its coarse bin IN EVERY PENDING PASS
 //       and inserted / probed with LDS atomics, the slice is written back once.
 //       Transactional per bucket: a bucket that overflows is left untouched in
 //       HBM and flagged; the host grows the table and replays those buckets
@@ -32,7 +37,7 @@
 
 #define KB_THREADS   1024
 #define KB_F_BITS    8                   // preferred fine radix (level 2)
-#define KB_F_BITS_MAX 9                  // used only when the table has more buckets than 2^(C1_MAX+8)
+#define KB_F_BITS_MAX 10                 // 9 / 10: only when the table has more buckets than 2^(9 + 8) / 2^(10 + 9)
 #define KB_F         (1 << KB_F_BITS_MAX)  // LDS array size for the fine histogram
 #define KB_C1_MAX    10                  // coarse bins <= 1024
 #define KB_MAX_PASS  64                  // pending passes one kernel C can apply
@@ -65,46 +70,69 @@ static_assert(KB_C_THREADS % 256 == 0 && KB_C_THREADS <= 1024 && KB_C_THREADS_W 
 #define KB_C_CT(KW) ((KW) == 2 ? KB_C_THREADS_W : KB_C_THREADS)
 #define KB_C_RUNS    256                 // runs (chunks of the coarse bin) staged per round
 
+// Threads of the slab kernel: 1024 x 16 windows = 16 K-entry slabs (132 KB of LDS, one workgroup per CU).  512 (8 K slabs,
+// two workgroups per CU) measured 4.03 ms against 3.14 for the slab kernel and 6.7 against 5.5 for the piece kernel, whose
+// gathers are runs of SLAB / bins entries: 128 bytes instead of 256.
+#ifndef KB_A_THREADS
+#define KB_A_THREADS 1024
+#endif
 template <int KW> struct KbCfg;
-template <> struct KbCfg<1> { static constexpr int WPT = 16, CHUNK = 16384; };   // 8-byte entries: 128 KB of LDS
-// (WPT = 8 for narrow keys -- 8 K slabs, two workgroups per CU at 8 waves per SIMD -- was measured at 8.6 ms for A1
-// against 4.6: the runs halve and 64 VGPRs spill.)
-template <> struct KbCfg<2> { static constexpr int WPT = 8,  CHUNK = 8192;  };   // 16-byte entries
+// WPT windows per thread of the slab kernel; SLAB stream positions (= entries at most) per slab; CHUNK = capacity of a piece
+#ifndef KB_CHUNK_N
+#define KB_CHUNK_N 16384
+#endif
+template <> struct KbCfg<1> { static constexpr int WPT = 16, SLAB = KB_A_THREADS * 16, CHUNK = KB_CHUNK_N; };       // 8-byte entries: a piece is 128 KB of LDS
+template <> struct KbCfg<2> { static constexpr int WPT = 8,  SLAB = KB_A_THREADS * 8,  CHUNK = KB_CHUNK_N / 2;  };   // 16-byte entries
 // Wide entries travel as 16-byte (h, hi) structs: one dwordx4 / ds_*_b128 per entry instead
-// of two 8-byte accesses to two arrays (runs are short: 9 entries in A1, 16 in C).
+// of two 8-byte accesses to two arrays (runs are short).
 struct __attribute__((aligned(16))) KbEnt2 { uint64_t lo, hi; };
+#ifndef KB_G_MAX
+#define KB_G_MAX 1024                    // slabs per group (one thread of the piece kernel per slab)
+#endif
 
 struct KbPlan {
     uint32_t c1;            // coarse bits
     uint32_t c2;            // fine bits (<= KB_F_BITS_MAX)
     uint32_t sub_bits;      // table buckets per partition bucket = 2^sub_bits (a table that grew since the partition: more)
     uint32_t log2cap, bucket_bits;
-    uint32_t off_stride;    // entries per row of chunk_off = 2^c2 + 1
-    uint32_t key_parts, key_part;   // KdfTable::key_parts: windows of other key-space slices are dropped in A0 / A1
+    uint32_t off_stride;    // words per row of chunk_off = 2^KB_F_BITS_MAX + 1 (fixed: the rows of passes of any geometry share the array)
+    uint32_t key_parts, key_part;   // KdfTable::key_parts: windows of other key-space slices are dropped in A
     uint32_t dbg;           // experiments only
     uint32_t n_pass;        // pending passes kernel C applies (1 .. KB_MAX_PASS)
+    uint32_t group;         // G: slabs per group
+    uint32_t n_groups, n_slabs;
 };
 
-// One partitioned pass in the ring (device resident, written by kb_scan1_kernel).
+// One partitioned pass in the ring (device resident, written by kb_binfirst_kernel).  Pieces are numbered BIN-MAJOR: the
+// pieces of bin c are rows row_base + binrow_first[c] .. binrow_first[c + 1]) and lie one after the other in the ring.
 struct KbPass {
     unsigned long long ent_base;                          // first entry of the pass in the ring (entries)
-    unsigned long long chunk_base;                        // first row of the pass in chunk_off
-    unsigned long long n_entries, n_chunks;
-    unsigned long long bin_start[(1 << KB_C1_MAX) + 1];   // first entry of each coarse bin, relative to ent_base
-    unsigned long long chunk_first[(1 << KB_C1_MAX) + 1]; // first chunk of each coarse bin, relative to chunk_base
+    unsigned long long row_base;                          // first row of the pass (chunk_off, row_ent, row_len)
+    unsigned long long n_entries, n_rows;
+    uint32_t binrow_first[(1 << KB_C1_MAX) + 1];          // rows of the bins before bin c
+    unsigned long long binent_first[(1 << KB_C1_MAX) + 1];// entries of the bins before bin c
 };
 
 // device scratch shared by the kernels of the binned path
 struct KbScratch {
-    unsigned long long *hist1;      // [2^c1] (per pass, between A0 and A1)
-    uint32_t *hist_wg;              // [n_wg][2^c1] per-workgroup coarse histogram
-    uint32_t *wg_base;              // [n_wg][2^c1] exclusive prefix of hist_wg over the workgroups
-    unsigned long long *totals;     // [16]: 0 entries (all pending passes), 2 failed buckets, 4 heavy buckets, 7 skew flag
-    unsigned int *failed_flag;      // [1]: set when a scatter pass disagrees with its histogram pass
-    uint32_t *chunk_off;            // [chunks in the ring][2^c2 + 1]
-    uint32_t *failed;               // bitmap over TABLE buckets
-    uint64_t *ent;                  // the entry ring: stored forms h; wide keys: (h, hi) pairs, 16 B each
+    // the pass being partitioned (reused by the next pass)
+    uint64_t *tmp;                  // [n_slabs][SLAB] slab-sorted entries (wide: 16-byte pairs)
+    uint16_t *off;                  // [n_slabs][2^c1 + 1] bin offsets inside each slab (last = its valid windows)
+    uint32_t *gn;                   // [n_groups][2^c1] entries of the pair (group g, bin c)
+    uint32_t *gpre_row;             // [n_groups][2^c1] pieces of bin c in the groups before g
+    unsigned long long *gpre_ent;   // [n_groups][2^c1] entries of bin c in the groups before g
+    uint32_t *bin_rows;             // [2^c1] pieces of bin c
+    unsigned long long *bin_ent;    // [2^c1] entries of bin c
+    uint32_t *ovf;                  // [0] = pieces beyond the first of their pair (skew), then (pair, piece) couples
+    uint32_t ovf_cap, pad_;
+    // the ring
+    uint64_t *ent;                  // entries: stored forms h; wide keys: (h, hi) pairs, 16 B each
+    uint32_t *chunk_off;            // [rows][off_stride] fine-run offsets of every sorted piece
+    unsigned long long *row_ent;    // [rows] first entry of the piece (absolute)
+    uint32_t *row_len;              // [rows] its entries
     KbPass *pass;                   // [KB_MAX_PASS]
+    unsigned long long *totals;     // [16]: 0 entries (all pending passes), 2 failed buckets, 4 heavy buckets, 7 skew flag
+    uint32_t *failed;               // bitmap over TABLE buckets
     // heavy buckets of a skewed flush (kb_heavy_slice_kernel): [0] how many, their ids, staged (key, count) pairs
     uint32_t *hv_ctr;               // [4]
     uint32_t *hv_bucket, *hv_n, *hv_failed;   // [KB_HV_MAX]
@@ -237,143 +265,47 @@ struct KbWindows {
     }
 };
 
-// A0: persistent workgroups.  Workgroup w owns slabs [w*spw, (w+1)*spw) in BOTH
-// passes; it accumulates its coarse-bin histogram in LDS over all its slabs and
-// writes ONE row hist_wg[w][bin] (no global atomics).
-template <int KW, bool SLICED>
-__global__ __launch_bounds__(KB_THREADS) void kb_hist1_kernel(
-    const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid, uint64_t n_tiles, int k,
-    KbPlan plan, KbScratch s, uint32_t slabs_per_wg)
-{
-    __shared__ uint32_t hist[(1 << KB_C1_MAX) + 1];           // last = dummy counter of invalid windows
-    constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT;      // threads per tile
-    constexpr uint32_t TILES_PER_SLAB = KB_THREADS / TPT;
-    const int nb = 1 << plan.c1;
-    for (int i = threadIdx.x; i < nb; i += KB_THREADS) hist[i] = 0;
-    __syncthreads();
-    const uint64_t slab0 = (uint64_t)blockIdx.x * slabs_per_wg;
-    for (uint32_t sl = 0; sl < slabs_per_wg; ++sl) {
-        const uint64_t tile = (slab0 + sl) * TILES_PER_SLAB + threadIdx.x / TPT;
-        if ((slab0 + sl) * TILES_PER_SLAB >= n_tiles) break;
-        KbWindows<KW> win;
-        win.load(packed, invalid, tile, n_tiles, threadIdx.x % TPT, k);
-#pragma unroll
-        for (int u = 0; u < WPT; ++u) {
-            uint64_t hsh, hi; win.stored(u, hsh, hi);
-            const bool ok = ((win.valid >> u) & 1) && (!SLICED || kdf_slice(hsh, plan.key_parts) == plan.key_part);
-            const uint32_t bin = ok ? kb_coarse(plan, hsh) : (uint32_t)(1 << KB_C1_MAX);   // dummy counter
-            atomicAdd(&hist[bin], 1u);
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nb; i += KB_THREADS) s.hist_wg[(uint64_t)blockIdx.x * nb + i] = hist[i];
-}
-
-// column scan: block b = coarse bin b; exclusive prefix over the workgroups ->
-// wg_base[w][b] (offset of workgroup w inside bin b) and the bin total hist1[b]
-__global__ __launch_bounds__(256) void kb_colscan_kernel(KbPlan plan, KbScratch s, uint32_t n_wg) {
-    __shared__ uint32_t wsum[32];
-    const int nb = 1 << plan.c1;
-    const uint32_t b = blockIdx.x;
-    unsigned long long carry = 0;
-    for (uint32_t w0 = 0; w0 < n_wg; w0 += 256) {
-        const uint32_t w = w0 + threadIdx.x;
-        const uint32_t v = w < n_wg ? s.hist_wg[(uint64_t)w * nb + b] : 0;
-        uint32_t tot = 0;
-        const uint32_t ex = kb_block_exscan(v, wsum, &tot);
-        if (w < n_wg) s.wg_base[(uint64_t)w * nb + b] = carry + ex;
-        carry += tot;
-    }
-    if (threadIdx.x == 0) s.hist1[b] = carry;
-}
-
-// single workgroup: bin starts and chunk layout of pass `pass_idx`, whose entries start at ent_base of the ring and
-// whose chunk_off rows start at chunk_base (both chosen by the host from upper bounds: no host round trip)
-__global__ __launch_bounds__(KB_THREADS) void kb_scan1_kernel(KbPlan plan, KbScratch s, uint32_t pass_idx, unsigned long long ent_base,
-                                                              unsigned long long chunk_base, uint32_t chunk, KdfCtl *ctl) {
-    __shared__ unsigned long long a[(1 << KB_C1_MAX) + 1], c[(1 << KB_C1_MAX) + 1];
-    const int nb = 1 << plan.c1;
-    KbPass *P = s.pass + pass_idx;
-    if (threadIdx.x == 0) {
-        unsigned long long acc = 0, cacc = 0;
-        for (int i = 0; i < nb; ++i) {
-            a[i] = acc; c[i] = cacc;
-            const unsigned long long n = s.hist1[i];
-            acc += n; cacc += (n + chunk - 1) / chunk;
-        }
-        a[nb] = acc; c[nb] = cacc;
-        unsigned long long mx = 0;
-        for (int i = 0; i < nb; ++i) mx = s.hist1[i] > mx ? s.hist1[i] : mx;
-        // skewed: one coarse bin holds more than twice its share (a uniform hash keeps the bins within a few per cent)
-        if (nb > 1 && mx * (unsigned long long)nb > 2 * acc + 65536ull * nb) s.totals[7] = 1ull;
-        s.totals[0] += acc;
-        P->ent_base = ent_base; P->chunk_base = chunk_base; P->n_entries = acc; P->n_chunks = cacc;
-        if (acc) atomicAdd(&ctl->windows[0], acc);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i <= nb; i += KB_THREADS) { P->bin_start[i] = a[i]; P->chunk_first[i] = c[i]; }
-}
-
-// A1: same slab ownership as A0.  Each workgroup keeps a private cursor per bin
-// (bin_start + wg_base, advanced slab by slab): no global atomics, deterministic
-// layout.  Per slab: rank the windows with LDS atomics, counting-sort them into
-// an LDS image, then copy out run by run (a half-wave per bin) so that every
-// (workgroup, bin) run is one contiguous global write.
 // Barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0),
-// i.e. waits for every outstanding global store; in the persistent scatter
-// kernel (one workgroup per CU) that serialises the copy-out's HBM writes with
-// the next slab's compute.  The barriers there protect LDS data only.
+// i.e. waits for every outstanding global store; in the slab kernel that would
+// serialise a slab's write-out with the next slab's compute.  The barriers there protect LDS data only.
 __device__ __forceinline__ void kb_lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
 
+// A: the stream is read ONCE.  A workgroup takes slabs_per_wg consecutive slabs; per slab: stored form + coarse bin of
+// every window, rank by LDS atomics, counting sort into an LDS image, the image written out CONTIGUOUSLY to
+// tmp[slab * SLAB ...] and the slab's offset row to off[slab][0 .. nbins] (off[slab][nbins] = its valid windows).
 template <int KW, bool SLICED>
-__global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
+__global__ __launch_bounds__(KB_A_THREADS) void kb_slabsort_kernel(
     const uint64_t *__restrict__ packed, const uint64_t *__restrict__ invalid, uint64_t n_tiles, int k,
-    KbPlan plan, KbScratch s, uint32_t pass_idx, uint32_t slabs_per_wg)
+    KbPlan plan, KbScratch s, uint32_t slabs_per_wg)
 {
-    constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT, SLAB = KB_THREADS * WPT;
-    constexpr uint32_t TILES_PER_SLAB = KB_THREADS / TPT;
+    constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT, SLAB = KbCfg<KW>::SLAB, NT = KB_A_THREADS;
+    constexpr uint32_t TILES_PER_SLAB = NT / TPT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t *slo = (uint64_t *)smem;                                   // [SLAB + 1]: last = trash slot
-    KbEnt2 *s2 = (KbEnt2 *)smem;                                        // [SLAB + 1] wide: the image holds (h, hi) pairs
-    KbEnt2 *const ent2 = (KbEnt2 *)s.ent;
-    unsigned long long *gcur = (unsigned long long *)(smem + (size_t)(SLAB + 2) * 8 * KW);   // next free entry of this WG per bin
-    unsigned long long *gend = gcur + (1 << KB_C1_MAX);                 // end of this WG's range (guard)
-    uint32_t *hist = (uint32_t *)(gend + (1 << KB_C1_MAX));             // [bins + 1]: last = dummy counter of invalid windows
-    uint32_t *offs = hist + (1 << KB_C1_MAX) + 32;                      // [bins + 1]: offs[DUMMY] = trash slot
-    constexpr int DUMMY = 1 << KB_C1_MAX;
+    uint64_t *slo = (uint64_t *)smem;                                   // [SLAB + 2]: [SLAB] = trash slot
+    KbEnt2 *s2 = (KbEnt2 *)smem;                                        // wide: the image holds (h, hi) pairs
+    uint32_t *hist = (uint32_t *)(smem + (size_t)(SLAB + 2) * 8 * KW);  // [bins + 1 ..]: [DUMMY] = counter of invalid windows
+    uint32_t *offs = hist + (1 << KB_C1_MAX) + 32;                      // [bins + 1 ..]: offs[DUMMY] = trash slot
+    constexpr int DUMMY = (1 << KB_C1_MAX) + 1;             // (index 2^c1 <= 1024 holds the slab's total)
     const int nb = 1 << plan.c1;
-    const KbPass *P = s.pass + pass_idx;
-    if (threadIdx.x == 0) { hist[DUMMY] = 0; offs[DUMMY] = (uint32_t)SLAB; }
-    for (int i = threadIdx.x; i < nb; i += KB_THREADS) {
-        hist[i] = 0;
-        const unsigned long long st = P->ent_base + P->bin_start[i] + s.wg_base[(uint64_t)blockIdx.x * nb + i];
-        gcur[i] = st;
-        gend[i] = st + s.hist_wg[(uint64_t)blockIdx.x * nb + i];
-    }
+    for (int i = threadIdx.x; i <= DUMMY; i += NT) hist[i] = 0;
+    if (threadIdx.x == 0) offs[DUMMY] = (uint32_t)SLAB;
     __syncthreads();
     const uint64_t slab0 = (uint64_t)blockIdx.x * slabs_per_wg;
-    constexpr int GL = 2 * WPT;                                         // lanes that copy one bin's run = its mean length (wide keys: 16 lanes instead of 32 took A1 from 8.9 to 7.9 ms)
-    const int half = threadIdx.x / GL, lane32 = threadIdx.x % GL;
-    constexpr int NHALF = KB_THREADS / GL;
-    // Four barriers per slab (a 16-wave workgroup alone on its CU pays the skew of
-    // its slowest wave at every barrier): rank | scan by ONE wave | LDS scatter |
-    // copy-out + cursor update.  The next slab's input words are fetched before
-    // the current slab is processed, so waves do not reach the first barrier
-    // skewed by global-load latency.
     if (slab0 * TILES_PER_SLAB >= n_tiles) return;                     // uniform
     KbWindows<KW> win;
     win.load(packed, invalid, slab0 * TILES_PER_SLAB + threadIdx.x / TPT, n_tiles, threadIdx.x % TPT, k);
     for (uint32_t sl = 0; sl < slabs_per_wg; ++sl) {
-        if ((slab0 + sl) * TILES_PER_SLAB >= n_tiles) break;          // uniform
+        const uint64_t slab = slab0 + sl;
+        if (slab * TILES_PER_SLAB >= n_tiles) break;                  // uniform
         KbWindows<KW> nxt;
         {
-            // prefetch: loads only; (tile >= n_tiles handles "no next slab")
+            // prefetch of the next slab's words: loads only; (tile >= n_tiles handles "no next slab")
             const bool more = sl + 1 < slabs_per_wg;
-            nxt.issue(packed, invalid, more ? (slab0 + sl + 1) * TILES_PER_SLAB + threadIdx.x / TPT : n_tiles,
+            nxt.issue(packed, invalid, more ? (slab + 1) * TILES_PER_SLAB + threadIdx.x / TPT : n_tiles,
                       n_tiles, threadIdx.x % TPT, k);
         }
         // Branch-free ranking: invalid windows (~4 %) go to a dummy counter
@@ -403,6 +335,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
             for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if ((int)threadIdx.x >= o) inc += t; }
             uint32_t run = inc - sum;
             for (int i = 0; i < per; ++i) if (b0 + i < nb) { offs[b0 + i] = run; run += hist[b0 + i]; }
+            if (threadIdx.x == 63) offs[nb] = inc;                      // the slab's valid windows
         }
         kb_lds_barrier();                                               // B2: offsets ready
         {
@@ -419,80 +352,214 @@ __global__ __launch_bounds__(KB_THREADS) void kb_scatter1_kernel(
                 else slo[pos[u]] = klo[u];
             }
         }
-        // retire the prefetched words of the next slab BEFORE any store is issued:
+        // the slab's offset row (coalesced) while the image settles; the histogram is zeroed for the next slab
+        {
+            uint16_t *orow = s.off + slab * (uint64_t)(nb + 1);
+            for (int i = threadIdx.x; i <= nb; i += NT) { orow[i] = (uint16_t)offs[i]; hist[i] = 0; }
+            if (threadIdx.x == 0) hist[DUMMY] = 0;
+        }
+        // retire the prefetched words of the next slab BEFORE the write-out is issued:
         // vmcnt retires in order, so a later wait for these loads would also wait
         // for every store issued in between
         nxt.finish();
         asm volatile("" :: "v"(nxt.e[0]), "v"(nxt.e[1]), "v"(nxt.valid));
         kb_lds_barrier();                                               // B3: sorted image complete
-        for (int bin = half; bin < nb; bin += NHALF) {
-            const uint32_t n = hist[bin], o = offs[bin];
-            const unsigned long long g = gcur[bin];
-            if (g + n > gend[bin]) {           // the stream changed between the passes: never write past the range
-                if (lane32 == 0 && n) s.failed_flag[0] = 1;
+        {
+            // ONE contiguous block per slab: 16 bytes per lane and step
+            const uint32_t nv = offs[nb];
+            if constexpr (KW == 2) {
+                KbEnt2 *dst = (KbEnt2 *)s.tmp + slab * (uint64_t)SLAB;
+                for (uint32_t i = threadIdx.x; i < nv; i += NT) dst[i] = s2[i];
             } else {
-                for (uint32_t i = lane32; i < n; i += GL) {
-                    if constexpr (KW == 2) ent2[g + i] = s2[o + i];
-                    else s.ent[g + i] = slo[o + i];
-                }
+                ulonglong2 *dst = (ulonglong2 *)(s.tmp + slab * (uint64_t)SLAB);
+                const ulonglong2 *src = (const ulonglong2 *)slo;
+                for (uint32_t i = threadIdx.x; i < (nv + 1) / 2; i += NT) dst[i] = src[i];      // (SLAB is even: the odd tail stays inside the slab's block)
             }
-            if (lane32 == 0) { gcur[bin] = g + n; hist[bin] = 0; }      // this half-wave owns the bin
         }
-        if (threadIdx.x == 0) hist[DUMMY] = 0;
-        kb_lds_barrier();                                               // B4: hist is zero, image free (stores still draining)
+        kb_lds_barrier();                                               // B4: image free (stores still draining)
         win = nxt;
     }
 }
 
-// B: one workgroup per chunk of pass `pass_idx`; in-place sort by fine bin + offset table
+// P1: entries of every (group, bin) pair: column sums over the group's offset rows
+// (grid: groups x ceil(bins / 64); a workgroup = 64 bins x 4 quarters of the group's rows, eight rows in flight per
+// thread: the kernel is a chain of dependent-latency loads otherwise -- 0.66 ms for 190 workgroups of 952 rows each)
+__global__ __launch_bounds__(256) void kb_groupsum_kernel(KbPlan plan, KbScratch s) {
+    __shared__ uint32_t part[256];
+    const uint32_t nb = 1u << plan.c1, g = blockIdx.x;
+    const uint64_t s0 = (uint64_t)g * plan.group;
+    const uint32_t ns = (uint32_t)min((uint64_t)plan.group, (uint64_t)plan.n_slabs - s0);
+    const uint32_t c = blockIdx.y * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    uint32_t acc = 0;
+    if (c < nb) {
+        const uint32_t i0 = (uint32_t)((uint64_t)ns * q / 4), i1 = (uint32_t)((uint64_t)ns * (q + 1) / 4);
+        const uint16_t *o = s.off + (s0 + i0) * (nb + 1) + c;
+        uint32_t i = i0;
+        for (; i + 8 <= i1; i += 8) {
+            uint32_t a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a[u] = o[(size_t)u * (nb + 1)]; b[u] = o[(size_t)u * (nb + 1) + 1]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += b[u] - a[u];
+            o += (size_t)8 * (nb + 1);
+        }
+        for (; i < i1; ++i, o += nb + 1) acc += (uint32_t)o[1] - (uint32_t)o[0];
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (q == 0 && c < nb) s.gn[(uint64_t)g * nb + c] = part[threadIdx.x] + part[threadIdx.x + 64] + part[threadIdx.x + 128] + part[threadIdx.x + 192];
+    if (g == 0 && blockIdx.y == 0 && threadIdx.x == 0) s.ovf[0] = 0;
+}
+
+// P2: workgroup = bin c: prefix over the groups of the bin's pieces and entries (a pair (g, c) of n entries is
+// ceil(n / CHUNK) pieces: one, unless the input is skewed); the pieces beyond a pair's first are listed for B's second launch
+template <int CHUNK>
+__global__ __launch_bounds__(256) void kb_binscan_kernel(KbPlan plan, KbScratch s) {
+    __shared__ uint32_t wsum[32];
+    __shared__ unsigned long long esum[256];
+    const uint32_t nb = 1u << plan.c1, c = blockIdx.x;
+    uint32_t carry_r = 0; unsigned long long carry_e = 0;
+    for (uint32_t g0 = 0; g0 < plan.n_groups; g0 += 256) {
+        const uint32_t g = g0 + threadIdx.x;
+        const uint64_t pair = (uint64_t)g * nb + c;
+        const uint32_t n = g < plan.n_groups ? s.gn[pair] : 0u, np = (n + CHUNK - 1) / CHUNK;
+        uint32_t tot = 0;
+        const uint32_t ex = kb_block_exscan(np, wsum, &tot);
+        // entries: 64-bit sums, a serial prefix over the 4 waves' totals after a wave scan
+        unsigned long long inc = n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_up(inc, o); if ((int)(threadIdx.x & 63) >= o) inc += t; }
+        esum[threadIdx.x] = inc;
+        __syncthreads();
+        unsigned long long wpre = 0;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) wpre += esum[w * 64 + 63];
+        const unsigned long long etot = esum[63] + esum[127] + esum[191] + esum[255];
+        if (g < plan.n_groups) {
+            s.gpre_row[pair] = carry_r + ex;
+            s.gpre_ent[pair] = carry_e + wpre + inc - n;
+            if (np > 1) {
+                const uint32_t at = atomicAdd(&s.ovf[0], np - 1);
+                for (uint32_t p = 1; p < np; ++p) if (at + p - 1 < s.ovf_cap) { s.ovf[1 + 2 * (at + p - 1)] = (uint32_t)pair; s.ovf[2 + 2 * (at + p - 1)] = p; }
+            }
+        }
+        carry_r += tot; carry_e += etot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { s.bin_rows[c] = carry_r; s.bin_ent[c] = carry_e; }
+}
+
+// P3 (one workgroup): prefix over the bins -> the pass descriptor.  The pass's entries start at ent_base of the ring and
+// its rows at row_base (chosen by the host from upper bounds: no host round trip).
+__global__ __launch_bounds__(KB_THREADS) void kb_binfirst_kernel(KbPlan plan, KbScratch s, uint32_t pass_idx, unsigned long long ent_base,
+                                                                 unsigned long long row_base, KdfCtl *ctl) {
+    __shared__ uint32_t wsum[32];
+    __shared__ unsigned long long esum[KB_THREADS];
+    const uint32_t nb = 1u << plan.c1;
+    KbPass *P = s.pass + pass_idx;
+    const uint32_t r = threadIdx.x < nb ? s.bin_rows[threadIdx.x] : 0u;
+    const unsigned long long e = threadIdx.x < nb ? s.bin_ent[threadIdx.x] : 0ull;
+    uint32_t tot_r = 0;
+    const uint32_t ex = kb_block_exscan(r, wsum, &tot_r);
+    unsigned long long inc = e;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_up(inc, o); if ((int)(threadIdx.x & 63) >= o) inc += t; }
+    esum[threadIdx.x] = inc;
+    __syncthreads();
+    unsigned long long wpre = 0, tot_e = 0;
+    for (uint32_t w = 0; w < KB_THREADS / 64; ++w) { const unsigned long long v = esum[w * 64 + 63]; if (w < (threadIdx.x >> 6)) wpre += v; tot_e += v; }
+    if (threadIdx.x < nb) {
+        P->binrow_first[threadIdx.x] = ex; P->binent_first[threadIdx.x] = wpre + inc - e;
+        // skewed: one coarse bin holds more than twice its share (a uniform hash keeps the bins within a few per cent)
+        if (nb > 1 && e * (unsigned long long)nb > 2 * tot_e + 65536ull * nb) s.totals[7] = 1ull;
+    }
+    if (threadIdx.x == 0) {
+        P->binrow_first[nb] = tot_r; P->binent_first[nb] = tot_e;
+        P->ent_base = ent_base; P->row_base = row_base; P->n_entries = tot_e; P->n_rows = tot_r;
+        s.totals[0] += tot_e;
+        if (tot_e) atomicAdd(&ctl->windows[0], tot_e);
+    }
+}
+
+// B: one piece: gather its runs (one per slab of its group), sort by fine bin, append to the ring with
+// the piece's offset row.  All threads of the workgroup call it.
+// The gather is FLAT: thread t takes the piece's entries t', t' + 64, ... of its wave's 64 * EPT consecutive entries, so a
+// load instruction reads 64 consecutive entries (two or three runs of ~32) and all EPT loads of a thread are in flight
+// together -- one global latency per piece.  The run of an entry is found by interpolation for a lane's first entry and by
+// advancing for the next ones (a lane's consecutive entries are ~2 runs apart).  (A first version gave every run to a
+// group of 32 lanes and staged the gathered entries in LDS: runs longer than 32 took a second, dependent load, a group of
+// more than 512 slabs a second round of loads, and the kernel ran at 5.5-6.7 ms against 3.9 for round 2's in-place sort.)
 template <int KW>
-__global__ __launch_bounds__(KB_THREADS) void kb_finesort_kernel(KbPlan plan, KbScratch s, uint32_t pass_idx)
+__device__ __forceinline__ void kb_sort_piece(const KbPlan &plan, const KbScratch &s, const KbPass *P, char *smem, uint32_t pair, uint32_t p)
 {
-    constexpr int CHUNK = KbCfg<KW>::CHUNK, EPT = CHUNK / KB_THREADS;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CHUNK = KbCfg<KW>::CHUNK, EPT = CHUNK / KB_THREADS, SLAB = KbCfg<KW>::SLAB;
     uint64_t *slo = (uint64_t *)smem;
     KbEnt2 *s2 = (KbEnt2 *)smem;
-    KbEnt2 *const ent2 = (KbEnt2 *)s.ent;
-    uint32_t *hist = (uint32_t *)(smem + (size_t)CHUNK * 8 * KW);       // [256]
-    uint32_t *offs = hist + KB_F;                                        // [256]
+    uint32_t *hist = (uint32_t *)(smem + (size_t)CHUNK * 8 * KW);       // [KB_F]
+    uint32_t *offs = hist + KB_F;                                        // [KB_F]
     uint32_t *wsum = offs + KB_F;                                        // [32]
-    unsigned long long &sh_start = *(unsigned long long *)(wsum + 32);
-    uint32_t &sh_len = *(uint32_t *)(wsum + 34);
-    const KbPass *P = s.pass + pass_idx;
-    const uint64_t chunk = blockIdx.x;
-    if (chunk >= P->n_chunks) return;                       // the grid covers the largest possible number of chunks
-    if (threadIdx.x == 0) {
-        // locate the coarse bin of this chunk: chunk_first is ascending
-        const int nb = 1 << plan.c1;
-        int lo = 0, hi = nb;            // largest c with chunk_first[c] <= chunk
-        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (P->chunk_first[mid] <= chunk) lo = mid; else hi = mid; }
-        const unsigned long long st = P->bin_start[lo] + (chunk - P->chunk_first[lo]) * (unsigned long long)CHUNK;
-        const unsigned long long en = P->bin_start[lo + 1];
-        sh_start = P->ent_base + st;
-        sh_len = (uint32_t)((en - st) < (unsigned long long)CHUNK ? (en - st) : (unsigned long long)CHUNK);
-    }
+    unsigned long long *rsrc = (unsigned long long *)(wsum + 32);       // [KB_G_MAX] entry index in tmp of the run's first entry MINUS the run's position in the pair
+    uint32_t *rpre = (uint32_t *)(rsrc + KB_G_MAX);                     // [KB_G_MAX + 4] position of the run's first entry in the pair's sequence; padded with the total
+    const uint32_t nb = 1u << plan.c1;
+    const uint32_t g = pair / nb, c = pair % nb;
+    const uint32_t n_pair = s.gn[pair];
+    if (n_pair <= p * (uint32_t)CHUNK) return;                          // an empty pair has no piece (uniform)
+    const uint32_t lo_ = p * (uint32_t)CHUNK, len = min((uint32_t)CHUNK, n_pair - lo_);   // the piece is [lo_, lo_ + len) of the pair's entries
+    const uint64_t row = P->row_base + P->binrow_first[c] + s.gpre_row[pair] + p;
+    const unsigned long long dst0 = P->ent_base + P->binent_first[c] + s.gpre_ent[pair] + lo_;
     const int nf = 1 << plan.c2;
     for (int i = threadIdx.x; i < KB_F; i += KB_THREADS) hist[i] = 0;
+    // the run of slab s0 + t in bin c
+    const uint64_t s0 = (uint64_t)g * plan.group;
+    const uint32_t ns = (uint32_t)min((uint64_t)plan.group, (uint64_t)plan.n_slabs - s0);
+    uint32_t o0 = 0, rl = 0;
+    if (threadIdx.x < ns) {
+        const uint16_t *o = s.off + (s0 + threadIdx.x) * (uint64_t)(nb + 1) + c;
+        o0 = o[0]; rl = (uint32_t)o[1] - o0;
+    }
+    const uint32_t pre = kb_block_exscan(rl, wsum, nullptr);            // (barriers inside: hist is zeroed)
+    if (threadIdx.x < ns) {
+        rsrc[threadIdx.x] = (s0 + threadIdx.x) * (unsigned long long)SLAB + o0 - pre;
+        rpre[threadIdx.x] = pre;
+    }
+    if (threadIdx.x >= ns && threadIdx.x < ns + 4) rpre[threadIdx.x] = n_pair;       // (threads past the last run: pre == the pair's total)
+    if (threadIdx.x == 0) { s.row_ent[row] = dst0; s.row_len[row] = len; }
     __syncthreads();
-    const unsigned long long start = sh_start;
-    const uint32_t len = sh_len;
-    const unsigned long long row = (P->chunk_base + chunk) * plan.off_stride;
     uint64_t klo[EPT], khi[KW == 2 ? EPT : 1];
     uint32_t br[EPT];
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const uint32_t i = e * KB_THREADS + threadIdx.x;
-        if (i < len) {
-            if constexpr (KW == 2) { const KbEnt2 v = ent2[start + i]; klo[e] = v.lo; khi[e] = v.hi; }
-            else klo[e] = s.ent[start + i];
+    {
+        const KbEnt2 *tmp2 = (const KbEnt2 *)s.tmp;
+        const uint32_t wbase = (threadIdx.x >> 6) * (64 * EPT) + (threadIdx.x & 63);   // this lane's first entry of the piece
+        uint32_t cr = 0, cnx = 0;                                       // current run and the position (in the pair) where the next one starts
+        unsigned long long cs = 0;
+        if (wbase < len) {
+            const uint32_t e = lo_ + wbase;
+            uint32_t gu = (uint32_t)(((unsigned long long)e * ns) / n_pair);           // runs have nearly equal lengths: interpolate, then walk
+            gu = gu < ns ? gu : ns - 1;
+            while (rpre[gu] > e) --gu;
+            while (rpre[gu + 1] <= e) ++gu;                             // (rpre[ns] = n_pair > e: stops at the last run)
+            cr = gu; cnx = rpre[cr + 1]; cs = rsrc[cr];
         }
-    }
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const uint32_t i = e * KB_THREADS + threadIdx.x;
-        if (i < len) {
-            const uint32_t f = kb_fine(plan, klo[e]);                   // the entry is the hash
-            br[e] = (f << 16) | atomicAdd(&hist[f], 1u);
+        for (int q = 0; q < EPT; ++q) {
+            const uint32_t i = wbase + 64 * q;
+            klo[q] = 0; if constexpr (KW == 2) khi[q] = 0;
+            if (i < len) {
+                const uint32_t e = lo_ + i;
+                if (e >= cnx) {
+                    do { ++cr; cnx = rpre[cr + 1]; } while (e >= cnx);
+                    cs = rsrc[cr];
+                }
+                if constexpr (KW == 2) { const KbEnt2 v = tmp2[cs + e]; klo[q] = v.lo; khi[q] = v.hi; }
+                else klo[q] = s.tmp[cs + e];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const uint32_t i = wbase + 64 * q;
+            if (i < len) {
+                const uint32_t f = kb_fine(plan, klo[q]);               // the entry is the hash
+                br[q] = (f << 16) | atomicAdd(&hist[f], 1u);
+            }
         }
     }
     __syncthreads();
@@ -501,29 +568,57 @@ __global__ __launch_bounds__(KB_THREADS) void kb_finesort_kernel(KbPlan plan, Kb
         const uint32_t ex = kb_block_exscan(v, wsum, nullptr);
         if (threadIdx.x < nf) {
             offs[threadIdx.x] = ex;
-            s.chunk_off[row + threadIdx.x] = ex;
+            s.chunk_off[row * plan.off_stride + threadIdx.x] = ex;
         }
-        if (threadIdx.x == 0) s.chunk_off[row + nf] = len;
+        if (threadIdx.x == 0) s.chunk_off[row * plan.off_stride + nf] = len;
     }
     __syncthreads();
+    {
+        const uint32_t wbase = (threadIdx.x >> 6) * (64 * EPT) + (threadIdx.x & 63);
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const uint32_t i = e * KB_THREADS + threadIdx.x;
-        if (i < len) {
-            const uint32_t pos = offs[br[e] >> 16] + (br[e] & 0xFFFF);
-            if constexpr (KW == 2) s2[pos] = KbEnt2{klo[e], khi[e]};
-            else slo[pos] = klo[e];
+        for (int q = 0; q < EPT; ++q) {
+            if (wbase + 64 * q < len) {
+                const uint32_t pos = offs[br[q] >> 16] + (br[q] & 0xFFFF);
+                if constexpr (KW == 2) s2[pos] = KbEnt2{klo[q], khi[q]};
+                else slo[pos] = klo[q];
+            }
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < len; i += KB_THREADS) {
-        if constexpr (KW == 2) {
-            // the sorted chunk goes back as chunk-local structure of arrays -- len h words, then len hi
-            // words, in the same 16 * len bytes -- because kernel C's gathers run faster on two 8-byte
-            // streams than on 16-byte entries (measured: 15.5 vs 17.0 ms at k = 63)
+    if constexpr (KW == 2) {
+        // the sorted piece is stored as piece-local structure of arrays -- len h words, then len hi
+        // words, in the same 16 * len bytes -- because kernel C's gathers run faster on two 8-byte
+        // streams than on 16-byte entries (measured: 15.5 vs 17.0 ms at k = 63)
+        for (uint32_t i = threadIdx.x; i < len; i += KB_THREADS) {
             const KbEnt2 v = s2[i];
-            s.ent[2 * start + i] = v.lo; s.ent[2 * start + len + i] = v.hi;
-        } else s.ent[start + i] = slo[i];
+            s.ent[2 * dst0 + i] = v.lo; s.ent[2 * dst0 + len + i] = v.hi;
+        }
+    } else {
+        for (uint32_t i = threadIdx.x; i < len; i += KB_THREADS) s.ent[dst0 + i] = slo[i];
+    }
+}
+
+// first launch: workgroup = pair (g, c), its first piece.  Workgroups are dealt to the 8 XCDs round robin by blockIdx
+// and each XCD has its own L2: an XCD takes a contiguous eighth of the pairs, in (group, bin) order, so a group's offset
+// rows (~1 MB) are fetched into one L2 once and hit there by the group's other pieces.  (grid = 8 * ceil(pairs / 8))
+template <int KW>
+__global__ __launch_bounds__(KB_THREADS) void kb_piecesort_kernel(KbPlan plan, KbScratch s, uint32_t pass_idx)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t n_pairs = plan.n_groups << plan.c1, eighth = gridDim.x >> 3;
+    const uint32_t pair = (blockIdx.x & 7) * eighth + (blockIdx.x >> 3);
+    if (pair >= n_pairs) return;
+    kb_sort_piece<KW>(plan, s, s.pass + pass_idx, smem, pair, 0);
+}
+// second launch: the pieces beyond a pair's first (skewed input only); a few persistent workgroups walk the list
+template <int KW>
+__global__ __launch_bounds__(KB_THREADS) void kb_piecesort_more_kernel(KbPlan plan, KbScratch s, uint32_t pass_idx)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t n = min(s.ovf[0], s.ovf_cap);
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        kb_sort_piece<KW>(plan, s, s.pass + pass_idx, smem, s.ovf[1 + 2 * i], s.ovf[2 + 2 * i]);
+        __syncthreads();
     }
 }
 
@@ -539,12 +634,12 @@ __device__ __forceinline__ void kb_lds_sat_add(uint32_t *p, uint32_t add) {
 // The runs of partition bucket (c, f) over every pending pass, as ONE flat list r = 0 .. n_runs - 1 (run = the bucket's
 // slice of one sorted chunk).  setup(): per pass the bin's first chunk row / first entry / end in LDS (one global latency
 // for all passes); locate(): run r -> (first entry, length, wide keys: distance from the h words to the hi words).
-#define KB_RI_LDS_BYTES ((KB_MAX_PASS + 2) * 4 + 3 * KB_MAX_PASS * 8)
+#define KB_RI_LDS_BYTES ((KB_MAX_PASS + 2) * 4 + KB_MAX_PASS * 8)
 struct KbRunIndex {
-    uint32_t *ppref;                 // [KB_MAX_PASS + 1] runs of this bin before pass m
-    unsigned long long *prow, *pent, *pend;   // [KB_MAX_PASS] chunk_off row of the bin's first chunk / its first entry / the bin's end
+    uint32_t *ppref;                 // [KB_MAX_PASS + 1] runs (pieces) of this bin before pass m
+    unsigned long long *prow;        // [KB_MAX_PASS] row of the bin's first piece in pass m
     __device__ __forceinline__ void bind(char *p) {
-        prow = (unsigned long long *)p; pent = prow + KB_MAX_PASS; pend = pent + KB_MAX_PASS; ppref = (uint32_t *)(pend + KB_MAX_PASS);
+        prow = (unsigned long long *)p; ppref = (uint32_t *)(prow + KB_MAX_PASS);
     }
     // all threads of the workgroup call it (it ends with a barrier); returns the number of runs
     __device__ __forceinline__ uint32_t setup(const KbPlan &plan, const KbScratch &s, uint32_t c) {
@@ -552,11 +647,9 @@ struct KbRunIndex {
             uint32_t n = 0;
             if (threadIdx.x < plan.n_pass) {
                 const KbPass *P = s.pass + threadIdx.x;
-                const unsigned long long j0 = P->chunk_first[c], j1 = P->chunk_first[c + 1];
-                n = (uint32_t)(j1 - j0);
-                prow[threadIdx.x] = P->chunk_base + j0;
-                pent[threadIdx.x] = P->ent_base + P->bin_start[c];
-                pend[threadIdx.x] = P->ent_base + P->bin_start[c + 1];
+                const uint32_t j0 = P->binrow_first[c], j1 = P->binrow_first[c + 1];
+                n = j1 - j0;
+                prow[threadIdx.x] = P->row_base + j0;
             }
             uint32_t inc = n;
 #pragma unroll
@@ -570,21 +663,19 @@ struct KbRunIndex {
     template <int KW>
     __device__ __forceinline__ void locate(const KbPlan &plan, const KbScratch &s, uint32_t f, uint32_t r,
                                            unsigned long long &first, uint32_t &len, uint32_t &hioff) const {
-        constexpr int CHUNK = KbCfg<KW>::CHUNK;
         uint32_t m = 0;
         if (plan.n_pass > 1) {                                  // largest m with ppref[m] <= r
             uint32_t lo = 0, hi = plan.n_pass;
             while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ppref[mid] <= r) lo = mid; else hi = mid; }
             m = lo;
         }
-        const uint32_t j = r - ppref[m];                        // chunk of the bin inside pass m
-        const unsigned long long row = (prow[m] + j) * plan.off_stride;
-        const uint32_t r0 = s.chunk_off[row + f], r1 = s.chunk_off[row + f + 1];
+        const unsigned long long row = prow[m] + (r - ppref[m]);      // the r-th piece of the bin
+        const unsigned long long orow = row * plan.off_stride;
+        const uint32_t r0 = s.chunk_off[orow + f], r1 = s.chunk_off[orow + f + 1];
         len = r1 - r0;
-        const unsigned long long cs = pent[m] + (unsigned long long)j * CHUNK;      // first entry of the chunk
-        if constexpr (KW == 2) {                                // wide: word index of the run's h words; the hi words follow the chunk's h words
-            const unsigned long long left = pend[m] - cs;
-            hioff = (uint32_t)(left < (unsigned long long)CHUNK ? left : (unsigned long long)CHUNK);
+        const unsigned long long cs = s.row_ent[row];           // first entry of the piece
+        if constexpr (KW == 2) {                                // wide: word index of the run's h words; the hi words follow the piece's h words
+            hioff = s.row_len[row];
             first = 2 * cs + r0;
         } else { hioff = 0; first = cs + r0; }
     }
@@ -713,8 +804,6 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
     // Workgroups are dealt to the 8 XCDs round robin by blockIdx, and each XCD has its own L2.  Neighbouring buckets
     // (f, f + 1 of one coarse bin) read neighbouring runs of the same chunks -- they share the cache line at every run
     // boundary and the lines of the offset table -- so an XCD takes a contiguous eighth of the buckets, in order.
-    if (s.failed_flag[0]) return;                              // a partition is not usable (the stream changed under it): the host knows
-
     const uint32_t nbk = gridDim.x;
     const uint64_t bucket = (nbk & 7) ? blockIdx.x : (uint64_t)(blockIdx.x & 7) * (nbk >> 3) + (blockIdx.x >> 3);   // table bucket
     const uint64_t pb = bucket >> plan.sub_bits;              // partition bucket holding its entries
@@ -1120,7 +1209,7 @@ __global__ __launch_bounds__(256) void kb_replay_kernel(KbPlan plan, KbScratch s
 // pass 20.1 -> 16.0 ms.
 __global__ __launch_bounds__(256) void kb_heavy_slice_kernel(KbPlan plan, KbScratch s) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (!s.hv_ctr || s.failed_flag[0]) return;
+    if (!s.hv_ctr) return;
     const uint32_t nh = min(s.hv_ctr[0], KB_HV_MAX), h = blockIdx.y, slice = blockIdx.x;
     if (h >= nh) return;
     const uint32_t B = 1u << plan.bucket_bits, bmask = B - 1;
@@ -1194,7 +1283,7 @@ __global__ __launch_bounds__(256) void kb_heavy_slice_kernel(KbPlan plan, KbScra
 
 __global__ __launch_bounds__(256) void kb_heavy_combine_kernel(KbPlan plan, KbScratch s, KdfTable t, KdfCtl *ctl, int table_nonempty) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (!s.hv_ctr || s.failed_flag[0]) return;
+    if (!s.hv_ctr) return;
     const uint32_t nh = min(s.hv_ctr[0], KB_HV_MAX), h = blockIdx.x;
     if (h >= nh) return;
     if (h == 0 && threadIdx.x == 0) s.totals[4] = s.hv_ctr[0];     // (statistics: heavy buckets of this flush; the first KB_HV_MAX were split)

@@ -441,15 +441,15 @@ struct kdf_engine {
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t stage_bytes[4] = {0, 0, 0, 0};
     // ---- binned (LDS-bucket) path: scratch + options -------------------------------------------------------------------
-    unsigned long long *kb_small = nullptr;   // hist1 | totals[16] | failed_flag
-    unsigned long long *kb_totals_host = nullptr;   // pinned [16 + KB_MAX_PASS]
-    void *kb_buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ring (entries), -, chunk_off, failed, hist_wg, wg_base
-    size_t kb_bytes[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long *kb_small = nullptr;   // totals[16]
+    unsigned long long *kb_totals_host = nullptr;   // pinned [16]
+    void *kb_buf[8] = {nullptr};                     // ring entries, tmp (slab-sorted pass), chunk_off, failed, off rows, pass planning, row tables
+    size_t kb_bytes[8] = {0};
     KbPass *kb_pass = nullptr;                       // [KB_MAX_PASS] descriptors of the pending passes (device)
     // The entry ring: A0/A1/B append a partitioned pass per call; kernel C applies all pending passes at once when the
     // table is needed or the ring is full (kb_flush).  Reserved by upper bounds (one entry per stream position), so no
     // host round trip sits between the stages.
-    uint64_t ring_entries = 0, ring_rows = 0;        // capacity: entries (8 B x kw each), rows of chunk_off
+    uint64_t ring_entries = 0, ring_rows = 0;        // capacity: entries (8 B x kw each), rows (pieces)
     uint64_t ring_used = 0, rows_used = 0;           // reserved by the pending passes
     uint32_t n_pass = 0;
     uint64_t pend_positions = 0;                     // stream positions of the pending passes (upper bound of their entries)
@@ -457,6 +457,7 @@ struct kdf_engine {
     bool pend_filtered = false;                      // the pending passes are count --if passes
     uint64_t stat_flushes = 0;
     double grow_ratio = 0.0;                         // new distinct keys per counted window at the last flush (0: unknown)
+    uint64_t dens_windows = 0, dens_positions = 0;   // valid windows / stream positions of every pass this engine has flushed: sizes the piece groups
     // L1: small insert batches are concatenated (packed) in a pending stream first; the partition runs over ~2^30 positions
     uint64_t *l1_packed = nullptr, *l1_mask = nullptr;
     uint64_t l1_cap_tiles = 0, l1_tiles = 0;
@@ -708,7 +709,7 @@ static int kb_reserve(kdf_engine *h, int i, size_t bytes, bool exact = false) {
 }
 
 // the partition geometry for a table: coarse / fine bits; sub_bits = what the bucket kernel resolves itself
-static KbPlan kb_make_plan(const KdfTable &t) {
+static KbPlan kb_make_plan(const kdf_engine *h, const KdfTable &t) {
     KbPlan p{};
     p.log2cap = t.log2cap; p.bucket_bits = t.bucket_bits;
     const uint32_t nb_bits = t.log2cap - t.bucket_bits;
@@ -716,18 +717,27 @@ static KbPlan kb_make_plan(const KdfTable &t) {
     // when the table has more buckets than that resolves
     p.c2 = std::min<uint32_t>(KB_F_BITS, nb_bits);
     p.c1 = std::min<uint32_t>(9, nb_bits - p.c2);
-    if (p.c1 + p.c2 < nb_bits) p.c2 = std::min<uint32_t>(KB_F_BITS_MAX, nb_bits - p.c1);   // fine runs halve: still >= 256 B
-    if (p.c1 + p.c2 < nb_bits) p.c1 = std::min<uint32_t>(KB_C1_MAX, nb_bits - p.c2);      // coarse runs halve: last resort
-    p.sub_bits = nb_bits - p.c1 - p.c2;
+    if (p.c1 + p.c2 < nb_bits) p.c2 = std::min<uint32_t>(9, nb_bits - p.c1);               // fine runs halve: still >= 256 B
+    if (p.c1 + p.c2 < nb_bits) p.c1 = std::min<uint32_t>(KB_C1_MAX, nb_bits - p.c2);      // coarse runs halve
+    if (p.c1 + p.c2 < nb_bits) p.c2 = std::min<uint32_t>(KB_F_BITS_MAX, nb_bits - p.c1);  // 128-byte fine runs: still cheaper than reading
+    p.sub_bits = nb_bits - p.c1 - p.c2;                                                    // every run once per sub-bucket
     p.off_stride = (1u << p.c2) + 1;
+    // Slabs per group: a piece (bin x group) is ~0.93 CHUNK entries.  Windows per stream position: what this engine has
+    // seen so far (150 bp reads at k = 31: 0.78), 1 before its first flush; a pass that turns out denser only gets some
+    // pairs of two pieces (kb_piecesort_more_kernel).
+    const uint64_t chunk = h->kw == 1 ? KbCfg<1>::CHUNK : KbCfg<2>::CHUNK, slab = h->kw == 1 ? KbCfg<1>::SLAB : KbCfg<2>::SLAB;
+    double dens = 1.0;
+    if (h->dens_positions >= (1u << 20)) dens = std::min(1.0, std::max(0.05, 1.03 * (double)h->dens_windows / (double)h->dens_positions));
+    p.group = (uint32_t)std::min<double>(KB_G_MAX, std::max<double>(1.0, 0.93 * (double)chunk * (double)((uint64_t)1 << p.c1) / ((double)slab * dens)));
     return p;
 }
 
 template <int KW>
-static int kb_set_lds_attrs(kdf_engine *h, size_t a1, size_t b, size_t c, size_t hv) {
-    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_scatter1_kernel<KW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a1));
-    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_scatter1_kernel<KW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a1));
-    HIPCHK(h, hipFuncSetAttribute((const void *)kb_finesort_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b));
+static int kb_set_lds_attrs(kdf_engine *h, size_t a, size_t b, size_t c, size_t hv) {
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_slabsort_kernel<KW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a));
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_slabsort_kernel<KW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a));
+    HIPCHK(h, hipFuncSetAttribute((const void *)kb_piecesort_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b));
+    HIPCHK(h, hipFuncSetAttribute((const void *)kb_piecesort_more_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b));
 #define KB_SETV(V) \
     HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_INSERT, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c)); \
     HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_FILTERED, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c));
@@ -743,14 +753,12 @@ static int kb_set_lds_attrs(kdf_engine *h, size_t a1, size_t b, size_t c, size_t
 
 static int table_rehash(kdf_engine *h, uint32_t new_log2);
 
-// the small device arrays of the binned path, allocated once per engine; fills the pointers of `s` that do not depend
-// on the ring
+// the small device arrays of the binned path, allocated once per engine; fills the pointers of `s` from the engine's buffers
 static int kb_scratch(kdf_engine *h, KbScratch &s) {
-    const int nb1 = 1 << KB_C1_MAX;
     if (!h->kb_small) {
-        HIPCHK(h, hipMalloc((void **)&h->kb_small, (size_t)(nb1 + 1 + 16 + 2) * 8));
-        HIPCHK(h, hipMemsetAsync(h->kb_small, 0, (size_t)(nb1 + 1 + 16 + 2) * 8, h->stream));
-        HIPCHK(h, hipHostMalloc((void **)&h->kb_totals_host, (16 + 2) * 8));
+        HIPCHK(h, hipMalloc((void **)&h->kb_small, 16 * 8));
+        HIPCHK(h, hipMemsetAsync(h->kb_small, 0, 16 * 8, h->stream));
+        HIPCHK(h, hipHostMalloc((void **)&h->kb_totals_host, 16 * 8));
         HIPCHK(h, hipMalloc((void **)&h->kb_pass, sizeof(KbPass) * KB_MAX_PASS));
     }
     if (h->kw == 1 && !h->kb_heavy) {                             // heavy buckets of skewed flushes (kb_heavy_slice_kernel): ~100 MB, once
@@ -759,40 +767,39 @@ static int kb_scratch(kdf_engine *h, KbScratch &s) {
         HIPCHK(h, hipMemsetAsync((char *)h->kb_heavy + pairs * 12, 0, (4 + 3 * KB_HV_MAX) * 4, h->stream));
     }
     s = KbScratch{};
-    s.hist1 = h->kb_small; s.totals = s.hist1 + (nb1 + 1);
-    s.failed_flag = (unsigned int *)(s.totals + 16);
+    s.totals = h->kb_small;
     s.pass = h->kb_pass;
     if (h->kw == 1 && h->kb_heavy) {
         const size_t pairs = (size_t)KB_HV_MAX * KB_HV_SLICES << 12;
         s.hv_key = (uint64_t *)h->kb_heavy; s.hv_cnt = (uint32_t *)(s.hv_key + pairs);
         s.hv_ctr = s.hv_cnt + pairs; s.hv_bucket = s.hv_ctr + 4; s.hv_n = s.hv_bucket + KB_HV_MAX; s.hv_failed = s.hv_n + KB_HV_MAX;
     }
-    s.ent = (uint64_t *)h->kb_buf[0];
+    s.ent = (uint64_t *)h->kb_buf[0]; s.tmp = (uint64_t *)h->kb_buf[1];
     s.chunk_off = (uint32_t *)h->kb_buf[2]; s.failed = (uint32_t *)h->kb_buf[3];
-    s.hist_wg = (uint32_t *)h->kb_buf[4]; s.wg_base = (uint32_t *)h->kb_buf[5];
+    s.off = (uint16_t *)h->kb_buf[4];
+    // row tables of the ring: row_ent u64 | row_len u32, ring_rows of each
+    s.row_ent = (unsigned long long *)h->kb_buf[6];
+    s.row_len = (uint32_t *)(s.row_ent + h->ring_rows);
     return KDF_OK;
 }
 
 // the ring is empty again: nothing pending, the flush-wide counters zeroed
 static int kb_ring_reset(kdf_engine *h) {
     h->n_pass = 0; h->ring_used = 0; h->rows_used = 0; h->pend_positions = 0;
-    if (h->kb_small) HIPCHK(h, hipMemsetAsync(h->kb_small + ((1 << KB_C1_MAX) + 1), 0, (16 + 2) * 8, h->stream));   // totals + failed_flag
+    if (h->kb_small) HIPCHK(h, hipMemsetAsync(h->kb_small, 0, 16 * 8, h->stream));
     return KDF_OK;
 }
 
-static uint64_t kb_chunk_entries(const kdf_engine *h) { return h->kw == 1 ? KbCfg<1>::CHUNK : KbCfg<2>::CHUNK; }
-// rows of chunk_off a ring of `entries` entries needs, whatever the passes are
-static uint64_t kb_rows_for(const kdf_engine *h, uint64_t entries) { return entries / kb_chunk_entries(h) + (uint64_t)KB_MAX_PASS * ((1 << KB_C1_MAX) + 1) + 1; }
-
 static int kb_flush_ring(kdf_engine *h);
 
-// Room for a pass of need_e entries (upper bound: its stream positions).  A full ring is applied to the table first; a
-// ring that was too small for the pending passes plus this one grows (doubling, up to the budget) while it is empty.
-static int kb_ring_make_room(kdf_engine *h, uint64_t need_e, uint32_t off_stride) {
+// Room for a pass of need_e entries (upper bound: its stream positions) in need_r pieces.  A full ring is applied to the
+// table first; a ring that was too small for the pending passes plus this one grows (doubling, up to the budget) while
+// it is empty.
+static int kb_ring_make_room(kdf_engine *h, uint64_t need_e, uint64_t need_r, uint32_t off_stride) {
     int rc;
-    const uint64_t need_r = need_e / kb_chunk_entries(h) + ((1 << KB_C1_MAX) + 1);
+    const uint64_t rows_cap = std::min<uint64_t>(h->ring_rows, h->kb_bytes[2] / ((uint64_t)off_stride * 4));
     bool forced = false;
-    if (h->n_pass >= KB_MAX_PASS || h->ring_used + need_e > h->ring_entries || h->rows_used + need_r > h->ring_rows) {
+    if (h->n_pass >= KB_MAX_PASS || h->ring_used + need_e > h->ring_entries || h->rows_used + need_r > rows_cap) {
         forced = h->n_pass > 0;
         if (h->n_pass && (rc = kb_flush_ring(h))) return rc;
     }
@@ -803,75 +810,87 @@ static int kb_ring_make_room(kdf_engine *h, uint64_t need_e, uint32_t off_stride
     if (need_e > want_e) want_e = std::max<uint64_t>(h->opt_defer ? std::max<uint64_t>(need_e, std::min<uint64_t>(2 * need_e, budget / esz)) : need_e, 1ull << 24);
     if (forced && h->opt_defer && h->ring_entries * esz < budget)
         want_e = std::max<uint64_t>(want_e, std::min<uint64_t>(2 * h->ring_entries, std::max<uint64_t>(budget / esz, need_e)));
-    // (rows are sized for the widest offset table, so a table that grows does not move the ring)
-    const uint64_t want_r = kb_rows_for(h, want_e);
-    if (want_e > h->ring_entries || want_r * ((1u << KB_F_BITS_MAX) + 1) * 4 > h->kb_bytes[2]) {
+    // pieces: in proportion to the entries (passes of one sample look alike), and never fewer than this pass needs
+    const uint64_t want_r = std::max<uint64_t>(need_r, (uint64_t)((double)need_r * ((double)want_e / (double)need_e))) + 4096;
+    if (want_e > h->ring_entries || need_r > rows_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
         if ((rc = kb_reserve(h, 0, want_e * esz, true))) return rc;
-        if ((rc = kb_reserve(h, 2, want_r * ((1u << KB_F_BITS_MAX) + 1) * 4, true))) return rc;
-        h->ring_entries = want_e; h->ring_rows = want_r;
+        if ((rc = kb_reserve(h, 2, want_r * (uint64_t)off_stride * 4, true))) return rc;
+        if ((rc = kb_reserve(h, 6, want_r * 12, true))) return rc;
+        h->ring_entries = std::max(h->ring_entries, want_e); h->ring_rows = std::max(h->ring_rows, want_r);
+        // (kb_reserve only ever grows a buffer: the row tables are laid out for ring_rows rows)
+        if (h->kb_bytes[6] < h->ring_rows * 12) return fail(h, KDF_ERR_STATE, "entry ring: row tables out of step");
     }
-    (void)off_stride;
     return KDF_OK;
 }
 
-// ONE partition pass (A0, A1, B) of a device-resident stream of at most opt_binned_max_positions positions into the ring
+// ONE partition pass (A, P, B) of a device-resident stream of at most opt_binned_max_positions positions into the ring
 template <int KW>
 static int kb_partition(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_invalid, uint64_t n_bases, bool filtered) {
-    constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT, CHUNK = KbCfg<KW>::CHUNK, SLAB = KB_THREADS * WPT;
+    constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT, CHUNK = KbCfg<KW>::CHUNK, SLAB = KbCfg<KW>::SLAB;
+    constexpr uint32_t TILES_PER_SLAB = KB_A_THREADS / TPT;
     const uint64_t n_tiles = (n_bases + KDF_TILE - 1) / KDF_TILE;
     if (n_tiles == 0) return KDF_OK;
     int rc;
     // pending passes must share their geometry, key slice and mode (kdf_set_option / a mode change flush first)
     if (h->n_pass && h->pend_filtered != filtered && (rc = kb_flush_ring(h))) return rc;
+    KbPlan plan = h->n_pass ? h->pend_plan : kb_make_plan(h, h->t);
+    if (h->n_pass == 0) { plan.key_parts = filtered ? 0 : h->t.key_parts; plan.key_part = h->t.key_part; }
+    const int nbins = 1 << plan.c1;
+    const uint64_t n_slabs = (n_tiles + TILES_PER_SLAB - 1) / TILES_PER_SLAB;
+    const uint64_t n_groups = (n_slabs + plan.group - 1) / plan.group;
     const uint64_t n_entries_max = n_tiles * KDF_TILE;
-    if ((rc = kb_ring_make_room(h, n_entries_max, 0))) return rc;
-    if (h->n_pass == 0) {
-        h->pend_plan = kb_make_plan(h->t);
-        h->pend_plan.key_parts = filtered ? 0 : h->t.key_parts; h->pend_plan.key_part = h->t.key_part;
-        h->pend_filtered = filtered;
-    }
-    KbPlan plan = h->pend_plan;
+    const uint64_t n_rows_max = n_groups * nbins + n_entries_max / CHUNK + 1;
+    if (n_rows_max >= (1ull << 32) || n_slabs >= (1ull << 31)) return fail(h, KDF_ERR_INVALID, "binned pass: too many positions for one pass");
+    if ((rc = kb_ring_make_room(h, n_entries_max, n_rows_max, plan.off_stride))) return rc;
+    if (h->n_pass == 0) { h->pend_plan = plan; h->pend_filtered = filtered; }
     plan.dbg = h->opt_debug_flags;
-    const int nb1 = 1 << KB_C1_MAX, nbins = 1 << plan.c1;
-    const size_t lds_b = (size_t)CHUNK * 8 * KW + (size_t)(2 * KB_F + 32) * 4 + 16;
-    const size_t lds_a1 = (size_t)(SLAB + 2) * 8 * KW + (size_t)nb1 * 16 + (size_t)(2 * (nb1 + 32) + 32) * 4;
+    plan.n_slabs = (uint32_t)n_slabs; plan.n_groups = (uint32_t)n_groups;
+    const int nb1 = 1 << KB_C1_MAX;
+    const size_t lds_a = (size_t)(SLAB + 2) * 8 * KW + (size_t)(2 * (nb1 + 32)) * 4;
+    const size_t lds_b = (size_t)CHUNK * 8 * KW + (size_t)(2 * KB_F + 32) * 4 + (size_t)KB_G_MAX * 12 + 32;
     if (!h->attrs_set[KW]) {                                   // once per engine
         const size_t lds_c = KB_C_LDS(KW, (KW == 1 ? 12 : 11));
-        if ((rc = kb_set_lds_attrs<KW>(h, lds_a1, lds_b, lds_c, ((size_t)12 << 12) + KB_RI_LDS_BYTES))) return rc;
+        if ((rc = kb_set_lds_attrs<KW>(h, lds_a, lds_b, lds_c, ((size_t)12 << 12) + KB_RI_LDS_BYTES))) return rc;
         h->attrs_set[KW] = true;
     }
-    // persistent A0/A1 workgroups: each owns slabs_per_wg consecutive slabs
-    const uint64_t n_slabs = (n_tiles + (KB_THREADS / TPT) - 1) / (KB_THREADS / TPT);
-    const uint32_t n_wg = (uint32_t)std::min<uint64_t>(n_slabs, 4096);
-    const uint32_t slabs_per_wg = (uint32_t)((n_slabs + n_wg - 1) / n_wg);
-    const unsigned grid_a = (unsigned)((n_slabs + slabs_per_wg - 1) / slabs_per_wg);
-    if ((rc = kb_reserve(h, 4, (size_t)grid_a * nbins * 4))) return rc;
-    if ((rc = kb_reserve(h, 5, (size_t)grid_a * nbins * 4))) return rc;
+    // the pass's own buffers: slab-sorted entries, offset rows, planning arrays (reused by the next pass: stream order)
+    if ((rc = kb_reserve(h, 1, n_slabs * (uint64_t)SLAB * 8 * KW))) return rc;
+    if ((rc = kb_reserve(h, 4, n_slabs * (uint64_t)(nbins + 1) * 2 + 64))) return rc;
+    const uint64_t n_pairs = n_groups * nbins;
+    const uint64_t ovf_cap = n_entries_max / CHUNK + 1;       // pieces beyond the first of their pair: sum (np - 1) <= entries / CHUNK
+    if ((rc = kb_reserve(h, 5, n_pairs * 16 + (size_t)nb1 * 12 + (2 * ovf_cap + 2) * 4 + 64))) return rc;
     KbScratch s;
     if ((rc = kb_scratch(h, s))) return rc;
+    s.gpre_ent = (unsigned long long *)h->kb_buf[5];
+    s.bin_ent = s.gpre_ent + n_pairs;
+    s.gn = (uint32_t *)(s.bin_ent + nb1); s.gpre_row = s.gn + n_pairs; s.bin_rows = s.gpre_row + n_pairs; s.ovf = s.bin_rows + nb1;
+    s.ovf_cap = (uint32_t)ovf_cap;
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     std::vector<hipEvent_t> sev;
     auto stamp = [&]() { if (h->prof) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, h->stream); sev.push_back(e); } };
     if (h->prof) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, h->stream); }
-    stamp();                                                   // start of A0
+    stamp();                                                   // start of A
 
     const uint32_t pass_idx = h->n_pass;
     const bool sliced = plan.key_parts > 1;
-    if (sliced) hipLaunchKernelGGL((kb_hist1_kernel<KW, true>), dim3(grid_a), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
-    else hipLaunchKernelGGL((kb_hist1_kernel<KW, false>), dim3(grid_a), dim3(KB_THREADS), 0, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
-    hipLaunchKernelGGL(kb_colscan_kernel, dim3(nbins), dim3(256), 0, h->stream, plan, s, (uint32_t)grid_a);
-    hipLaunchKernelGGL(kb_scan1_kernel, dim3(1), dim3(KB_THREADS), 0, h->stream, plan, s, pass_idx, (unsigned long long)h->ring_used,
-                       (unsigned long long)h->rows_used, (uint32_t)CHUNK, h->ctl);
+    // A: a workgroup takes a few consecutive slabs (the next slab's words are prefetched under the current one)
+    const uint32_t slabs_per_wg = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, n_slabs / ((uint64_t)h->n_cu * 8)));
+    const unsigned grid_a = (unsigned)((n_slabs + slabs_per_wg - 1) / slabs_per_wg);
+    if (sliced) hipLaunchKernelGGL((kb_slabsort_kernel<KW, true>), dim3(grid_a), dim3(KB_A_THREADS), lds_a, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
+    else hipLaunchKernelGGL((kb_slabsort_kernel<KW, false>), dim3(grid_a), dim3(KB_A_THREADS), lds_a, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, slabs_per_wg);
+    stamp();                                                   // end of A
+    hipLaunchKernelGGL(kb_groupsum_kernel, dim3((unsigned)n_groups, (unsigned)((nbins + 63) / 64)), dim3(256), 0, h->stream, plan, s);
+    hipLaunchKernelGGL(kb_binscan_kernel<CHUNK>, dim3((unsigned)nbins), dim3(256), 0, h->stream, plan, s);
+    hipLaunchKernelGGL(kb_binfirst_kernel, dim3(1), dim3(KB_THREADS), 0, h->stream, plan, s, pass_idx, (unsigned long long)h->ring_used,
+                       (unsigned long long)h->rows_used, h->ctl);
     HIPCHK(h, hipGetLastError());
-    stamp();                                                   // end of A0 (+ scans)
-    // No host round trip here: the pass's share of the ring is sized for one entry per position and B is launched over the
-    // largest number of chunks the bins can have (its workgroups beyond the real count leave at once).
-    const uint64_t n_chunks_max = n_entries_max / CHUNK + (uint64_t)nbins + 1;
-    if (sliced) hipLaunchKernelGGL((kb_scatter1_kernel<KW, true>), dim3(grid_a), dim3(KB_THREADS), lds_a1, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, pass_idx, slabs_per_wg);
-    else hipLaunchKernelGGL((kb_scatter1_kernel<KW, false>), dim3(grid_a), dim3(KB_THREADS), lds_a1, h->stream, d_packed, d_invalid, n_tiles, h->k, plan, s, pass_idx, slabs_per_wg);
-    stamp();                                                   // end of A1
-    hipLaunchKernelGGL(kb_finesort_kernel<KW>, dim3((unsigned)n_chunks_max), dim3(KB_THREADS), lds_b, h->stream, plan, s, pass_idx);
+    stamp();                                                   // end of the planning kernels
+    // No host round trip: the pass's share of the ring is sized for one entry per position; B's first launch has one
+    // workgroup per (group, bin) pair, its second walks the (usually empty) list of further pieces.
+    hipLaunchKernelGGL(kb_piecesort_kernel<KW>, dim3((unsigned)((n_pairs + 7) / 8 * 8)), dim3(KB_THREADS), lds_b, h->stream, plan, s, pass_idx);
+    hipLaunchKernelGGL(kb_piecesort_more_kernel<KW>, dim3((unsigned)std::min<uint64_t>(ovf_cap, (uint64_t)h->n_cu)), dim3(KB_THREADS), lds_b, h->stream, plan, s, pass_idx);
     stamp();                                                   // end of B
     HIPCHK(h, hipGetLastError());
     if (h->prof) {
@@ -881,7 +900,7 @@ static int kb_partition(kdf_engine *h, const uint64_t *d_packed, const uint64_t 
         h->prof_stage_ev.push_back(sev);
     }
     h->n_pass++;
-    h->ring_used += n_entries_max; h->rows_used += n_chunks_max;
+    h->ring_used += n_entries_max; h->rows_used += n_rows_max;
     h->pend_positions += n_entries_max;
     h->stat_binned_passes++;
     h->last_path = 1;
@@ -910,14 +929,10 @@ static int kb_flush_ring(kdf_engine *h) {
     if ((rc = kb_scratch(h, s))) return rc;
     const bool filtered = h->pend_filtered;
     // what the pending passes hold (entries, skew) and what the table holds now
-    HIPCHK(h, hipMemcpyAsync(h->kb_totals_host, s.totals, (16 + 2) * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->kb_totals_host, s.totals, 16 * 8, hipMemcpyDeviceToHost, h->stream));
     if ((rc = ctl_sync(h, nullptr))) return rc;
-    if (((unsigned int *)(h->kb_totals_host + 16))[0]) {
-        (void)kb_ring_reset(h);
-        return fail(h, KDF_ERR_STATE, "binned count: the read stream changed while it was being counted "
-                                      "(is another stream still writing it? synchronise before the call)");
-    }
     const uint64_t n_entries = h->kb_totals_host[0];
+    h->dens_windows += n_entries; h->dens_positions += h->pend_positions;
     const bool skewed = h->kb_totals_host[7] != 0 || (h->opt_debug_flags & 4096);          // (debug flag 4096 forces VAR 2: fuzzing)
     const uint64_t distinct_before = h->distinct;
     // Grow BEFORE the flush when the last flush's rate of new keys says the pending entries will not fit: growing now
@@ -980,7 +995,7 @@ static int kb_flush_ring(kdf_engine *h) {
         h->prof_tiles.push_back(0);                            // (its positions were counted with the partition passes)
         h->prof_stage_ev.push_back(sev);
     }
-    HIPCHK(h, hipMemcpyAsync(h->kb_totals_host, s.totals, (16 + 2) * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->kb_totals_host, s.totals, 16 * 8, hipMemcpyDeviceToHost, h->stream));
     bool full = false;
     if ((rc = ctl_sync(h, &full))) return rc;
     h->stat_flushes++;
@@ -1244,7 +1259,7 @@ void kdf_destroy(kdf_engine *h) {
     table_free(h->t);
     prof_collect(h);
     for (int i = 0; i < 4; ++i) if (h->stage[i]) (void)hipFree(h->stage[i]);
-    for (int i = 0; i < 6; ++i) if (h->kb_buf[i]) (void)hipFree(h->kb_buf[i]);
+    for (int i = 0; i < 8; ++i) if (h->kb_buf[i]) (void)hipFree(h->kb_buf[i]);
     if (h->l1_packed) (void)hipFree(h->l1_packed);
     if (h->l1_mask) (void)hipFree(h->l1_mask);
     if (h->kb_pass) (void)hipFree(h->kb_pass);
