@@ -37,7 +37,7 @@
 
 #define KB_THREADS   1024
 #define KB_F_BITS    8                   // preferred fine radix (level 2)
-#define KB_F_BITS_MAX 10                 // 9 / 10: only when the table has more buckets than 2^(9 + 8) / 2^(10 + 9)
+#define KB_F_BITS_MAX 9                  // used only when the table has more buckets than 2^(9 + 8)
 #define KB_F         (1 << KB_F_BITS_MAX)  // LDS array size for the fine histogram
 #define KB_C1_MAX    10                  // coarse bins <= 1024
 #define KB_MAX_PASS  64                  // pending passes one kernel C can apply
@@ -60,7 +60,8 @@
 #define KB_C_THREADS_W 512                // wide keys: 2048-slot buckets hold ~3 K entries; 512 x 8 covers them and three workgroups fit a CU
 #endif
 #ifndef KB_C_WQ_W
-#define KB_C_WQ_W 48                      // wide keys: queue entries per wave (18 B each)
+#define KB_C_WQ_W 40                      // wide keys: queue entries per wave (18 B each): with 40, three workgroups' LDS (52.8 KB each) fit a CU; 48 + the
+                                          // run index of round 3 = 53.9 KB left room for two (kernel C 10.3 -> 13.8 ms at k = 63)
 #endif
 #ifndef KB_C_WPE
 #define KB_C_WPE 6                       // waves per SIMD the register allocation aims at
@@ -521,7 +522,7 @@ __device__ __forceinline__ void kb_sort_piece(const KbPlan &plan, const KbScratc
         rsrc[threadIdx.x] = (s0 + threadIdx.x) * (unsigned long long)SLAB + o0 - pre;
         rpre[threadIdx.x] = pre;
     }
-    if (threadIdx.x >= ns && threadIdx.x < ns + 4) rpre[threadIdx.x] = n_pair;       // (threads past the last run: pre == the pair's total)
+    if (threadIdx.x < 4) rpre[ns + threadIdx.x] = n_pair;               // padding: the run search below stops there (ns may equal the thread count)
     if (threadIdx.x == 0) { s.row_ent[row] = dst0; s.row_len[row] = len; }
     __syncthreads();
     uint64_t klo[EPT], khi[KW == 2 ? EPT : 1];

@@ -719,8 +719,9 @@ static KbPlan kb_make_plan(const kdf_engine *h, const KdfTable &t) {
     p.c1 = std::min<uint32_t>(9, nb_bits - p.c2);
     if (p.c1 + p.c2 < nb_bits) p.c2 = std::min<uint32_t>(9, nb_bits - p.c1);               // fine runs halve: still >= 256 B
     if (p.c1 + p.c2 < nb_bits) p.c1 = std::min<uint32_t>(KB_C1_MAX, nb_bits - p.c2);      // coarse runs halve
-    if (p.c1 + p.c2 < nb_bits) p.c2 = std::min<uint32_t>(KB_F_BITS_MAX, nb_bits - p.c1);  // 128-byte fine runs: still cheaper than reading
-    p.sub_bits = nb_bits - p.c1 - p.c2;                                                    // every run once per sub-bucket
+    // (beyond 2^19 buckets kernel C reads every run once per sub-bucket: 10 fine bits -- 16-entry runs -- measured worse,
+    // 9.65 against 8.86 ms per 10 M reads into 2^32 slots)
+    p.sub_bits = nb_bits - p.c1 - p.c2;
     p.off_stride = (1u << p.c2) + 1;
     // Slabs per group: a piece (bin x group) is ~0.93 CHUNK entries.  Windows per stream position: what this engine has
     // seen so far (150 bp reads at k = 31: 0.78), 1 before its first flush; a pass that turns out denser only gets some

@@ -251,3 +251,29 @@ def test_path_choice_follows_batch_and_table_size():
     for name in ("direct", "binned", "auto-deferred"):
         assert dumps[name][2] == dumps["auto"][2]
         assert torch.equal(dumps[name][0], dumps["auto"][0]) and torch.equal(dumps[name][1], dumps["auto"][1])
+
+
+def test_widest_partition_geometry_binned_equals_direct():
+    """A table of 2^32 slots takes the widest partition the pipeline has (1024 coarse bins, 1024 fine bins, groups of
+    1024 slabs -- one run per thread of the piece kernel, the case in which round 3's first strong-scaling job read past
+    its run table); 300 k reads in two passes, deferred, against the direct path on a small table."""
+    import torch
+    from kmer_denovo_filter_amd import KmerEngine
+    ds = _dev_stream(300_000, seed=9)
+    dumps = []
+    for hint, force in ((1 << 31, 2), (1 << 24, 1)):
+        with KmerEngine(31, capacity_hint=hint) as e:
+            e.set_option("force_path", force)
+            third = ds.n_bases // 3 // 64 * 64
+            e.count_dev(ds.packed.data_ptr(), ds.invalid.data_ptr(), third)
+            e.flush()                                   # (the engine now knows the windows per position: groups of 1024 slabs from here on)
+            e.count_dev(ds.packed.data_ptr(), ds.invalid.data_ptr(), ds.n_bases)
+            e.count_dev(ds.packed.data_ptr(), ds.invalid.data_ptr(), third)
+            _, distinct, windows = e.stats()
+            if force == 2:
+                assert e.get_stat("log2cap") == 32 and e.get_stat("binned_passes") == 3 and e.get_stat("flushes") == 2
+            lo = torch.empty(distinct, dtype=torch.int64, device="cuda:0"); cnt = torch.empty(distinct, dtype=torch.int32, device="cuda:0")
+            n = e.export_ge_dev(0, lo.data_ptr(), None, cnt.data_ptr(), distinct, sorted_=True); e.synchronize()
+            dumps.append((lo[:n], cnt[:n], windows))
+    assert dumps[0][2] == dumps[1][2]
+    assert torch.equal(dumps[0][0], dumps[1][0]) and torch.equal(dumps[0][1], dumps[1][1])
