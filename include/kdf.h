@@ -244,6 +244,11 @@ int kdf_export_parts_dev(kdf_engine *h, uint32_t min_count, uint32_t parts, void
 int kdf_export_parts_packed_dev(kdf_engine *h, uint32_t min_count, uint32_t parts, void *d_buf, uint64_t cap_bytes,
                                 uint64_t *part_counts_out, uint64_t *part_bytes_out, uint64_t *n_out);
 
+/* The count of every listed key becomes counts[i] (device pointers; every key must be stored: KDF_ERR_INVALID
+ * otherwise).  How the sum of the ranks' `count --if` tallies goes back into each rank's table after the all-reduce
+ * (kmer_denovo_filter_amd/distributed.py; the reference's parent scan is one process, discovery/pipeline.py:377-443). */
+int kdf_set_counts_dev(kdf_engine *h, const void *d_keys_lo, const void *d_keys_hi, const void *d_counts, uint64_t n);
+
 /* ------------------------------------------------------ Module-3 scan ---- */
 
 /* Probe every window of a read stream against the table: bit i of hit_bits is
@@ -292,6 +297,14 @@ int kdf_canonical(const char *kmer, int k, uint64_t *lo, uint64_t *hi);
  * (core/bam_scanner.py:405-409: skip SECONDARY and DUPLICATE, keep the rest). */
 int kdf_bam_open(const char *path, uint32_t flag_off, int collapse, int threads,
                  kdf_reader **out);
+/* The same reader over ONE RANGE of the file: the BGZF blocks that hold the records are cut at parts - 1 byte offsets
+ * and the record stream at the first record boundary behind each cut -- the first QNAME-run boundary when runs are
+ * collapsed, so no run is split: the parts 0 .. parts - 1 together yield exactly the records kdf_bam_open yields, each
+ * once, whatever `parts` is, and a part only reads and inflates its own bytes.  This is how the read stream of one
+ * sample is sharded over the GPUs of a node (reads are independent units) and over several reader
+ * pipelines inside one process.  Record ordinals (kdf_reader_last_ordinals) count from the part's first record. */
+int kdf_bam_open_range(const char *path, uint32_t flag_off, int collapse, int threads,
+                       int part, int parts, kdf_reader **out);
 /* Multi-record FASTA (reference genome, plain or gzip) as a reader: one stream
  * record per sequence, any case, non-ACGT invalid.  A sequence longer than a
  * batch is continued in the next batch k-1 bases back, so no window is lost or

@@ -41,6 +41,7 @@ SYMBOLS = [
     ("kdf_upload_reads_async", c_int, [_P, c_int, _P, _P, c_uint64]),
     ("kdf_count_uploaded", c_int, [_P, c_int, c_int]),
     ("kdf_add_pairs_dev", c_int, [_P, _P, _P, _P, c_uint64]),
+    ("kdf_set_counts_dev", c_int, [_P, c_void_p, c_void_p, c_void_p, c_uint64]),
     ("kdf_add_pairs_multi_dev", c_int, [_P, c_uint32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_uint64)]),
     ("kdf_load_filter", c_int, [_P, _P, _P, c_uint64]),
     ("kdf_load_filter_dev", c_int, [_P, _P, _P, c_uint64]),
@@ -60,6 +61,7 @@ SYMBOLS = [
     ("kdf_pack_reads", c_int, [_P, _P, c_int64, _P, _P, _P, POINTER(c_uint64)]),
     ("kdf_canonical", c_int, [c_char_p, c_int, POINTER(c_uint64), POINTER(c_uint64)]),
     ("kdf_bam_open", c_int, [c_char_p, c_uint32, c_int, c_int, POINTER(_P)]),
+    ("kdf_bam_open_range", c_int, [c_char_p, c_uint32, c_int, c_int, c_int, c_int, POINTER(_P)]),
     ("kdf_fasta_open", c_int, [c_char_p, c_int, POINTER(_P)]),
     ("kdf_reader_next", c_int, [_P, c_uint64, c_int64, _P, _P, _P, POINTER(c_int64), POINTER(c_uint64)]),
     ("kdf_reader_last_meta", c_int, [_P, POINTER(POINTER(c_uint16)), POINTER(POINTER(c_int32)),

@@ -19,7 +19,7 @@ import time
 
 import numpy as np
 
-from .. import jf_io
+from .. import dist_env, jf_io
 from .._native import KdfError
 from ..engine import KmerEngine
 from ..kmer_fasta import read_kmer_fasta_keys
@@ -109,10 +109,31 @@ def _stream_bam(engine, bam_path, ref_fasta, threads, filtered):
             "jellyfish count failed: CRAM input needs htslib, which the MI355X engine does not link; "
             "convert to BAM (samtools view -b) first"
         )
-    # decode (reader thread + its inflate workers) | H2D from pinned buffers on a copy stream | count: three stages
-    # that overlap, where the reference's pipe overlaps samtools and jellyfish
-    with bam_reader(bam_path, max_bases=BATCH_BASES, max_reads=1 << 21, threads=max(1, threads)) as rd:
-        return stream_batches_overlapped(engine, rd, filtered)
+    # decode (reader threads + their inflate workers) | H2D from pinned buffers on a copy stream | count: three stages
+    # that overlap, where the reference's pipe overlaps samtools and jellyfish.  The file is read as BGZF RANGES cut on
+    # record (QNAME-run) boundaries (kdf_bam_open_range): a rank of a multi-GPU job takes its contiguous share of them
+    # -- reads are independent units, SURVEY.md section 8e -- and inside a process every range has its own inflate /
+    # chunk / parse pipeline (one pipeline's chunker is a serial stage: 2.0 Gbase/s whatever the thread count).
+    world, rank, _ = dist_env.world_rank()
+    local = _reader_pipelines(threads)
+    per = max(1, threads // local)
+    readers = []
+    try:
+        for j in range(local):
+            readers.append(bam_reader(bam_path, max_bases=BATCH_BASES, max_reads=1 << 21, threads=per,
+                                      part=rank * local + j, parts=world * local))
+        return stream_batches_overlapped(engine, readers, filtered)
+    finally:
+        for rd in readers:
+            rd.close()
+
+
+def _reader_pipelines(threads):
+    """Reader pipelines per process for ``threads`` host threads (KDF_READER_PIPELINES overrides): one per four threads."""
+    env = os.environ.get("KDF_READER_PIPELINES")
+    if env:
+        return max(1, int(env))
+    return max(1, min(16, int(threads) // 4))
 
 
 def _scan_parent_jellyfish(parent_bam, ref_fasta, kmer_fasta, kmer_size, parent_dir, threads=4,
@@ -128,15 +149,50 @@ def _scan_parent_jellyfish(parent_bam, ref_fasta, kmer_fasta, kmer_size, parent_
         lo, hi = read_kmer_fasta_keys(kmer_fasta, kmer_size)
         logger.info("  BAM stream -> MI355X count --if (k=%d, threads=%d, filter_kmers=%d)",
                     kmer_size, threads, len(lo))
-        with KmerEngine(kmer_size, capacity_hint=max(len(lo), 1)) as eng:
+        with KmerEngine(kmer_size, capacity_hint=max(len(lo), 1), device=_device()) as eng:
             eng.load_filter(lo, hi)
             _stream_bam(eng, parent_bam, ref_fasta, threads, filtered=True)
+            _merge_filter_counts(eng, lo, hi)                  # (several ranks: every table now holds the summed counts)
             logger.info("  Jellyfish counting complete (%s)", _format_elapsed(time.monotonic() - scan_start))
             flo, fhi, fcnt = eng.export_ge(1)
     except KdfError as e:
         raise RuntimeError(f"jellyfish count failed: {e}") from e
     kmers = keys_to_kmers(flo, fhi, kmer_size)
     return dict(zip(kmers, fcnt.tolist()))
+
+
+def _device():
+    """The GPU of this process: LOCAL_RANK under a launcher (one process per GPU), else 0."""
+    world, rank, host = dist_env.world_rank()
+    if world == 1 or host:
+        return 0
+    return int(os.environ.get("LOCAL_RANK", rank))
+
+
+def _merge_filter_counts(eng, lo, hi, dlo=None, dhi=None):
+    """After every rank counted its shard of a parent's reads against the replicated filter: ONE all-reduce(sum) of the
+    per-key counts (distributed.ShardedFilterCount: the `ncclAllReduce` of SURVEY.md section 8e), and the sums go back
+    into every rank's table (kdf_set_counts_dev), so that what follows -- `query`, `dump -L 1`, the index file -- is the
+    same on every rank as in a one-process run.  ``lo`` / ``hi``: the filter keys as host arrays, or ``dlo`` / ``dhi``
+    as device tensors.  One rank: nothing to do."""
+    world, rank, host = dist_env.world_rank()
+    if world == 1:
+        return
+    import torch
+    from .. import devkeys
+    from ..distributed import EngineOps, ShardedFilterCount
+    dev = torch.device("cuda", eng.device)
+    if dlo is None:
+        if len(lo) == 0:
+            return
+        dlo, dhi = devkeys.from_host(lo, hi, eng.wide, eng.device)
+    if dlo.numel() == 0:
+        return
+    merged = ShardedFilterCount(EngineOps(eng, dev), stage_through_host=host).merged_counts(dlo, dhi)
+    m32 = merged.to(torch.int32).contiguous()                # (values < 2^32: the bit pattern is the uint32 count)
+    torch.cuda.current_stream(dev).synchronize()
+    eng.set_counts_dev(dlo.data_ptr(), dhi.data_ptr() if dhi is not None else None, m32.data_ptr(), int(dlo.numel()))
+    eng.synchronize()
 
 
 def _count_fasta_to_index(fasta_path, kmer_size, out_path, capacity_hint, cmdline):

@@ -147,6 +147,20 @@ __global__ __launch_bounds__(256) void kdf_query_kernel(
     out[i] = (s == ~0ull) ? 0u : t.cnt[s];
 }
 
+// thread per key: the count of a STORED key becomes counts[i] (the merged counts of a sharded count --if go back into
+// every rank's table); a key that is not stored raises the error flag
+template <int KW>
+__global__ __launch_bounds__(256) void kdf_set_counts_kernel(
+    const uint64_t *__restrict__ klo, const uint64_t *__restrict__ khi, const uint32_t *__restrict__ counts, uint64_t n,
+    KdfTable t, KdfCtl *ctl)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t s = KW == 1 ? kdf_find_narrow(t, kdf_hash(klo[i], 0)) : kdf_find_wide(t, kdf_hash(klo[i], khi[i]), khi[i]);
+    if (s == ~0ull) atomicOr(&ctl->error, 2u);
+    else t.cnt[s] = counts[i];
+}
+
 // dump -L: count / append entries with cnt >= min_count.  Each wave owns a
 // chunk of EXPORT_ROWS x 64 consecutive slots: it counts its matches, reserves
 // its output range with ONE atomic, then re-reads the (cache-resident) chunk and
@@ -1662,6 +1676,27 @@ int kdf_add_pairs(kdf_engine *h, const uint64_t *keys_lo, const uint64_t *keys_h
     }
     return add_pairs_dev(h, (const uint64_t *)h->stage[2], (const uint64_t *)h->stage[3],
                          counts ? (const uint32_t *)h->stage[0] : nullptr, n);
+}
+
+int kdf_set_counts_dev(kdf_engine *h, const void *d_keys_lo, const void *d_keys_hi, const void *d_counts, uint64_t n) {
+    if (!h) return fail(nullptr, KDF_ERR_INVALID, "NULL engine");
+    if (n == 0) return KDF_OK;
+    if (!d_keys_lo || !d_counts || (h->kw == 2 && !d_keys_hi)) return fail(h, KDF_ERR_INVALID, "kdf_set_counts_dev: NULL pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = pending_flush(h))) return rc;
+    if ((rc = materialize(h))) return rc;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (h->kw == 1) hipLaunchKernelGGL(kdf_set_counts_kernel<1>, dim3(blocks), dim3(256), 0, h->stream, (const uint64_t *)d_keys_lo, (const uint64_t *)nullptr, (const uint32_t *)d_counts, n, h->t, h->ctl);
+    else hipLaunchKernelGGL(kdf_set_counts_kernel<2>, dim3(blocks), dim3(256), 0, h->stream, (const uint64_t *)d_keys_lo, (const uint64_t *)d_keys_hi, (const uint32_t *)d_counts, n, h->t, h->ctl);
+    HIPCHK(h, hipGetLastError());
+    bool bad = false;
+    if ((rc = ctl_sync(h, &bad))) return rc;
+    if (bad) {
+        HIPCHK(h, hipMemsetAsync(&h->ctl->error, 0, 4, h->stream));
+        return fail(h, KDF_ERR_INVALID, "kdf_set_counts_dev: a key is not stored in the table");
+    }
+    return KDF_OK;
 }
 
 int kdf_count_reads_filtered_dev(kdf_engine *h, const void *d_packed, const void *d_invalid, uint64_t n_bases) {

@@ -166,6 +166,7 @@ struct BgzfBlock {
     std::vector<uint8_t> data;     // inflated
     int cdata = 0;
     uint32_t isize = 0;
+    uint64_t file_off = 0;         // where the block starts in the file
     int state = 0;                 // 0 free, 1 queued, 2 done, 3 error
     std::string err;
 };
@@ -173,6 +174,7 @@ struct BgzfBlock {
 // read one raw BGZF block.  returns 0 ok, 1 eof, -1 error (msg in err)
 int bgzf_read_raw(FILE *fp, BgzfBlock &blk, std::string &err) {
     uint8_t hdr[18];
+    blk.file_off = (uint64_t)ftello(fp);
     size_t got = fread(hdr, 1, 18, fp);
     if (got == 0) return 1;
     if (got != 18 || hdr[0] != 0x1f || hdr[1] != 0x8b || hdr[2] != 8 || !(hdr[3] & 4)) { err = "not a BGZF block (bad gzip header)"; return -1; }
@@ -279,7 +281,7 @@ struct BgzfPool {
         }
     }
     // append the next block's bytes to `out`.  0 ok, 1 eof, -1 error (msg in err)
-    int next(std::vector<uint8_t> &out, std::string &err) {
+    int next(std::vector<uint8_t> &out, std::string &err, uint64_t *file_off = nullptr) {
         std::unique_lock<std::mutex> lk(mu);
         cv_done.wait(lk, [this] { return stop || (head < tail && ring[head % ring.size()].state >= 2) || (eof_read && head == tail); });
         if (stop) return 1;
@@ -290,6 +292,7 @@ struct BgzfPool {
         BgzfBlock &blk = ring[head % ring.size()];
         if (blk.state == 3) { err = blk.err; return -1; }
         lk.unlock();
+        if (file_off) *file_off = blk.file_off;
         out.insert(out.end(), blk.data.begin(), blk.data.end());
         lk.lock();
         blk.state = 0;
@@ -358,6 +361,12 @@ struct kdf_reader {
     bool eof = false;
     uint32_t flag_off = 0;
     bool collapse = false;
+    // ---- a reader of ONE RANGE of the file (kdf_bam_open_range): it ends at the first record boundary (QNAME-run
+    // boundary when runs are collapsed) at or after the first BGZF block whose file offset is >= range_hi
+    uint64_t range_hi = UINT64_MAX;    // none
+    uint64_t stop_pos = UINT64_MAX;    // position in the inflated stream (since this reader's start) where that block begins
+    uint64_t consumed_base = 0;        // inflated bytes dropped from inbuf by compaction: position of inbuf[0]
+    bool range_done = false;
     // collapse state (samtools bam2fq: best record per read part of a QNAME run)
     bool have_run = false;
     std::string run_name;
@@ -414,20 +423,25 @@ int bgzf_read_block(kdf_reader *r) {
     // compact the consumed prefix now and then
     if (!r->no_compact && r->inpos > (1u << 20) && r->inpos * 2 > r->inbuf.size()) {
         r->inbuf.erase(r->inbuf.begin(), r->inbuf.begin() + r->inpos);
+        r->consumed_base += r->inpos;
         r->inpos = 0;
     }
     std::string err;
     int rc;
+    const uint64_t before = r->consumed_base + r->inbuf.size();
+    uint64_t foff = 0;
     if (r->pool) {
-        rc = r->pool->next(r->inbuf, err);
+        rc = r->pool->next(r->inbuf, err, &foff);
     } else {
         rc = bgzf_read_raw(r->fp, r->blk, err);
+        foff = r->blk.file_off;
         if (rc == 0) {
             if (!bgzf_inflate(r->blk)) { rc = -1; err = r->blk.err; }
             else r->inbuf.insert(r->inbuf.end(), r->blk.data.begin(), r->blk.data.end());
         }
     }
     if (rc < 0) return rfail(r, -1, "%s", err.c_str());
+    if (rc == 0 && r->stop_pos == UINT64_MAX && foff >= r->range_hi) r->stop_pos = before;    // the range ends inside / after this block
     return rc;
 }
 
@@ -499,9 +513,10 @@ bool bam_find_sa(const uint8_t *a, const uint8_t *end, const char **val, size_t 
 }
 
 // parse the next raw alignment; returns 1 at EOF, 0 ok, <0 error.
-int bam_next_raw(kdf_reader *r, Record &rec, bool &has_qual) {
+int bam_next_raw(kdf_reader *r, Record &rec, bool &has_qual, uint64_t *start_pos = nullptr) {
     bool e;
     if (!bam_need(r, 4, &e)) return e ? -1 : 1;
+    if (start_pos) *start_pos = r->consumed_base + r->inpos;
     const int32_t bs = le32(r->inbuf.data() + r->inpos);
     if (bs < 32) { rfail(r, KDF_ERR_IO, "corrupt BAM record"); return -1; }
     if (!bam_need(r, 4 + (size_t)bs, &e)) { if (!e) rfail(r, KDF_ERR_IO, "truncated BAM record"); return -1; }
@@ -553,14 +568,18 @@ void flush_run(kdf_reader *r) {
 // fill r->ready with at least one record if any remain.  returns <0 on error.
 int bam_pump(kdf_reader *r) {
     while (r->ready.empty()) {
-        Record rec = grab(r); bool hq = false;
-        const int rc = bam_next_raw(r, rec, hq);
+        if (r->range_done) return 0;
+        Record rec = grab(r); bool hq = false; uint64_t at = 0;
+        const int rc = bam_next_raw(r, rec, hq, &at);
         if (rc < 0) return -1;
         if (rc == 1) { if (r->have_run) flush_run(r); return 0; }
+        const bool zone = at >= r->stop_pos;                     // past the range's end: only the run that straddles it is finished
+        if (zone && !r->collapse) { r->range_done = true; recycle(r, std::move(rec)); return 0; }
         if (rec.flag & r->flag_off) { recycle(r, std::move(rec)); continue; }
         if (!r->collapse) { r->ready.push_back(std::move(rec)); return 0; }
         if (!r->have_run || rec.name != r->run_name) {
             if (r->have_run) flush_run(r);
+            if (zone) { r->range_done = true; recycle(r, std::move(rec)); return 0; }      // the next range's first run
             r->run_name = rec.name; r->have_run = true;
         }
         const bool r1 = rec.flag & 0x40, r2 = rec.flag & 0x80;
@@ -643,6 +662,8 @@ void ParsePipe::chunk_loop() {
             const unsigned l_rn = p[8];
             const uint16_t flag = (uint16_t)(p[14] | (p[15] << 8));
             const bool kept = !(flag & r->flag_off);
+            const bool zone = r->consumed_base + r->inpos + rel >= r->stop_pos;   // past the end of this reader's range
+            if (zone && !r->collapse) { end = true; break; }
             bool boundary = true;                               // may the chunk end before this record?
             if (r->collapse && kept) {
                 const size_t nl = l_rn ? l_rn - 1 : 0;
@@ -651,6 +672,7 @@ void ParsePipe::chunk_loop() {
             } else if (r->collapse) {
                 boundary = false;                               // a dropped record inside a run does not end it
             }
+            if (zone && r->collapse && kept && boundary) { end = true; break; }   // the next range's first run
             if (nrec >= TARGET_RECORDS && boundary) break;      // this record opens the next chunk
             if (r->collapse && kept && boundary) { prev_name.assign((const char *)p + 32, l_rn ? l_rn - 1 : 0); have_prev = true; }
             rel += 4 + (size_t)bs;
@@ -837,6 +859,220 @@ int kdf_bam_open(const char *path, uint32_t flag_off, int collapse, int threads,
     if (threads > 1) r->pool.reset(new BgzfPool(r->fp, r->threads));
     int rc = bam_read_header(r);
     if (rc) { g_host_err = std::string(path) + ": " + r->err; kdf_reader_close(r); return rc; }
+    *out = r;
+    return KDF_OK;
+}
+
+// ---- a reader of one BGZF RANGE of a BAM ------------------------------------------------------------------------
+// The file's record blocks [data_off, file_size) are cut at parts - 1 byte offsets F_1 < F_2 < ...; the record stream is
+// cut accordingly at S(F) = the first record that STARTS in a BGZF block at file offset >= F -- or, when QNAME runs are
+// collapsed, the first KEPT record from there on whose name differs from the kept record before it, so that no run is
+// split.  Part p reads [S(F_p), S(F_p+1)): the union of the parts is the whole file, record for record, whatever `parts`
+// is.  The reader that ENDS at S(F) finds it by walking its records (kdf_reader::range_hi / stop_pos); the reader that
+// STARTS there has no record boundary to walk from: it inflates a little before F, finds a record start by the shape
+// of three consecutive records (what Hadoop-BAM's split guesser does), walks to S(F) and hands the real reader the
+// BGZF block and the offset inside it.
+namespace {
+
+struct MiniBgzf {                     // sequential inflate from a file offset, remembering where every block's bytes begin
+    FILE *fp; std::vector<uint8_t> buf; std::vector<std::pair<size_t, uint64_t>> blocks;   // (position in buf, file offset)
+    BgzfBlock blk; bool eof = false;
+    explicit MiniBgzf(FILE *f) : fp(f) {}
+    bool more(std::string &err) {         // append one block; false at end of file or on error (err set)
+        if (eof) return false;
+        const int rc = bgzf_read_raw(fp, blk, err);
+        if (rc != 0) { eof = true; return false; }
+        if (!bgzf_inflate(blk)) { err = blk.err; eof = true; return false; }
+        blocks.emplace_back(buf.size(), blk.file_off);
+        buf.insert(buf.end(), blk.data.begin(), blk.data.end());
+        return true;
+    }
+};
+
+// first BGZF block at file offset >= from: gzip magic with the BC subfield, confirmed by the block that follows it
+bool find_bgzf_block(FILE *fp, uint64_t from, uint64_t file_size, uint64_t &at) {
+    std::vector<uint8_t> w(1 << 17);
+    for (uint64_t base = from; base + 18 <= file_size;) {
+        const size_t n = (size_t)std::min<uint64_t>(w.size(), file_size - base);
+        if (fseeko(fp, (off_t)base, SEEK_SET) != 0 || fread(w.data(), 1, n, fp) != n) return false;
+        for (size_t i = 0; i + 18 <= n; ++i) {
+            if (w[i] != 0x1f || w[i + 1] != 0x8b || w[i + 2] != 8 || w[i + 3] != 4) continue;
+            if ((w[i + 10] | (w[i + 11] << 8)) != 6 || w[i + 12] != 'B' || w[i + 13] != 'C' || w[i + 14] != 2 || w[i + 15] != 0) continue;
+            const uint64_t bsize = (uint64_t)(w[i + 16] | (w[i + 17] << 8)) + 1, next = base + i + bsize;
+            if (next > file_size) continue;
+            if (next < file_size) {                             // the next block must look like one too
+                uint8_t h[4];
+                if (fseeko(fp, (off_t)next, SEEK_SET) != 0 || fread(h, 1, 4, fp) != 4) continue;
+                if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4) continue;
+            }
+            at = base + i; return true;
+        }
+        if (n < 18 + 1) break;
+        base += n - 17;
+    }
+    return false;
+}
+
+// does a BAM alignment record plausibly start at q?  returns its total length (4 + block_size), 0 if not, and
+// (size_t)-1 when the bytes at hand do not reach far enough to tell
+size_t plausible_record(const uint8_t *q, size_t avail, int32_t n_ref) {
+    if (avail < 36) return (size_t)-1;
+    const int32_t bs = le32(q);
+    if (bs < 32 || bs > (1 << 28)) return 0;
+    const uint8_t *p = q + 4;
+    const int32_t ref = le32(p), pos = le32(p + 4), l_seq = le32(p + 16), nref = le32(p + 20), npos = le32(p + 24);
+    const unsigned l_rn = p[8], n_cig = p[12] | (p[13] << 8);
+    if (ref < -1 || ref >= n_ref || nref < -1 || nref >= n_ref || pos < -1 || npos < -1 || l_seq < 0 || l_rn < 2) return 0;
+    const size_t need = 32 + (size_t)l_rn + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+    if (need > (size_t)bs) return 0;
+    if (avail < 36 + (size_t)l_rn) return (size_t)-1;
+    if (p[32 + l_rn - 1] != 0) return 0;                        // the name ends with its NUL ...
+    for (unsigned i = 0; i + 1 < l_rn; ++i) if (p[32 + i] < 0x21 || p[32 + i] > 0x7e) return 0;   // ... and is printable before it
+    return 4 + (size_t)bs;
+}
+
+// locate S(F) (see above).  found = false: the range starts past the last record.  data_block / data_uoff: the
+// virtual offset of the file's first record (a true record boundary: no guessing when the look-back reaches it).
+int locate_range_start(const char *path, uint64_t F, uint64_t file_size, int32_t n_ref, uint32_t flag_off, bool collapse,
+                       uint64_t data_block, size_t data_uoff, uint64_t &blk_off, size_t &uoff, bool &found, std::string &err) {
+    found = false;
+    FILE *fp = fopen(path, "rb");
+    if (!fp) { err = "cannot open the file again"; return KDF_ERR_IO; }
+    struct Closer { FILE *f; ~Closer() { fclose(f); } } closer{fp};
+    uint64_t blockF = 0;
+    if (!find_bgzf_block(fp, F, file_size, blockF)) return KDF_OK;       // nothing starts at or after F
+    for (uint64_t k = 2;; k *= 4) {
+        const uint64_t back = k * 65536;
+        uint64_t lb = F > back ? F - back : 0;
+        bool from_data_start = lb <= data_block;
+        if (!from_data_start) { uint64_t b = 0; if (!find_bgzf_block(fp, lb, file_size, b) || b >= blockF) from_data_start = true; else lb = b; }
+        if (from_data_start) lb = data_block;
+        if (fseeko(fp, (off_t)lb, SEEK_SET) != 0) { err = "seek failed"; return KDF_ERR_IO; }
+        MiniBgzf mz(fp);
+        // inflate up to blockF and a little beyond
+        size_t posF = (size_t)-1;
+        std::string e2;
+        while (posF == (size_t)-1 || mz.buf.size() < posF + (1u << 17)) {
+            if (!mz.more(e2)) break;
+            if (posF == (size_t)-1 && mz.blocks.back().second >= blockF) posF = mz.blocks.back().first;
+        }
+        if (!e2.empty()) { err = e2; return KDF_ERR_IO; }
+        if (posF == (size_t)-1) return KDF_OK;                            // (blockF vanished: treat as past the end)
+        // a record start at or before posF
+        size_t start = (size_t)-1;
+        if (from_data_start) start = data_uoff;
+        else {
+            // three records in a row that look like records (fewer only where the inflated bytes end)
+            auto chain_ok = [&](size_t o) {
+                size_t q = o;
+                for (int i = 0; i < 3; ++i) {
+                    const size_t len = plausible_record(mz.buf.data() + q, mz.buf.size() - q, n_ref);
+                    if (len == 0) return false;
+                    if (len == (size_t)-1) return i > 0;
+                    q += len;
+                    if (q >= mz.buf.size()) return true;
+                }
+                return true;
+            };
+            for (size_t o = 0; o < posF; ++o) if (chain_ok(o)) { start = o; break; }
+            if (start == (size_t)-1) continue;                            // (inside one huge record?) look further back
+        }
+        // walk the records to S(F)
+        size_t q = start; bool have_kept = false; std::string last_kept;
+        for (;;) {
+            while (mz.buf.size() - q < 4 || mz.buf.size() - q < 4 + (size_t)std::max(le32(mz.buf.data() + q), 0)) {
+                std::string e3;
+                if (!mz.more(e3)) { if (!e3.empty()) { err = e3; return KDF_ERR_IO; } return KDF_OK; }   // ran off the file: nothing starts in this range
+            }
+            const int32_t bs = le32(mz.buf.data() + q);
+            if (bs < 32) { err = "corrupt BAM record while locating a range start"; return KDF_ERR_IO; }
+            const uint8_t *p = mz.buf.data() + q + 4;
+            const unsigned l_rn = p[8];
+            const uint16_t flag = (uint16_t)(p[14] | (p[15] << 8));
+            const bool kept = !(flag & flag_off);
+            const size_t nl = l_rn ? l_rn - 1 : 0;
+            if (q >= posF) {
+                bool here = !collapse;
+                if (collapse && kept) {
+                    if (!have_kept && !from_data_start) break;           // no kept record seen before the cut: look further back
+                    here = !have_kept || last_kept.size() != nl || memcmp(last_kept.data(), p + 32, nl) != 0;
+                }
+                if (here) {
+                    // the block that holds byte q
+                    size_t bi = mz.blocks.size() - 1;
+                    while (mz.blocks[bi].first > q) --bi;
+                    blk_off = mz.blocks[bi].second; uoff = q - mz.blocks[bi].first; found = true;
+                    return KDF_OK;
+                }
+            }
+            if (kept) { last_kept.assign((const char *)p + 32, nl); have_kept = true; }
+            q += 4 + (size_t)bs;
+        }
+        // (fell out of the walk: retry with a longer look-back)
+    }
+}
+
+}  // namespace
+
+int kdf_bam_open_range(const char *path, uint32_t flag_off, int collapse, int threads, int part, int parts, kdf_reader **out) {
+    if (!path || !out) return rfail(nullptr, KDF_ERR_INVALID, "kdf_bam_open_range: NULL argument");
+    if (parts < 1 || part < 0 || part >= parts) return rfail(nullptr, KDF_ERR_INVALID, "kdf_bam_open_range: part %d of %d", part, parts);
+    *out = nullptr;
+    // the header (reference names, where the records begin) through a plain sequential reader
+    kdf_reader *hr = nullptr;
+    int rc = kdf_bam_open(path, flag_off, collapse, 1, &hr);
+    if (rc) return rc;
+    if (parts == 1) { kdf_reader_close(hr); return kdf_bam_open(path, flag_off, collapse, threads, out); }
+    // the first record's virtual offset: the header ended at inbuf[inpos]; the sequential reader appended whole blocks
+    uint64_t data_block = 0; size_t data_uoff = 0;
+    {
+        FILE *fp = fopen(path, "rb");
+        if (!fp) { kdf_reader_close(hr); return rfail(nullptr, KDF_ERR_IO, "cannot open %s", path); }
+        MiniBgzf mz(fp); std::string e;
+        const size_t hdr_end = hr->inpos;
+        while (mz.buf.size() <= hdr_end) if (!mz.more(e)) break;
+        fclose(fp);
+        if (!e.empty()) { kdf_reader_close(hr); return rfail(nullptr, KDF_ERR_IO, "%s: %s", path, e.c_str()); }
+        if (mz.buf.size() <= hdr_end) {                          // a BAM without records: part 0 reads it (nothing), the others are empty
+            kdf_reader_close(hr);
+            rc = kdf_bam_open(path, flag_off, collapse, 1, out);
+            if (rc == KDF_OK && part > 0) { (*out)->range_done = true; (*out)->eof = true; (*out)->inbuf.clear(); (*out)->inpos = 0; }
+            return rc;
+        }
+        size_t bi = mz.blocks.size() - 1;
+        while (mz.blocks[bi].first > hdr_end) --bi;
+        data_block = mz.blocks[bi].second; data_uoff = hdr_end - mz.blocks[bi].first;
+    }
+    const int32_t n_ref = (int32_t)hr->ref_names.size();
+    uint64_t file_size = 0;
+    { FILE *fp = fopen(path, "rb"); if (fp) { fseeko(fp, 0, SEEK_END); file_size = (uint64_t)ftello(fp); fclose(fp); } }
+    const uint64_t span = file_size > data_block ? file_size - data_block : 0;
+    auto cut = [&](int p) { return data_block + (uint64_t)((unsigned __int128)span * (unsigned)p / (unsigned)parts); };
+    uint64_t blk_off = data_block; size_t uoff = data_uoff; bool found = true;
+    std::string e;
+    if (part > 0) {
+        rc = locate_range_start(path, cut(part), file_size, n_ref, flag_off, collapse != 0, data_block, data_uoff, blk_off, uoff, found, e);
+        if (rc) { kdf_reader_close(hr); return rfail(nullptr, rc, "%s: %s", path, e.c_str()); }
+    }
+    // the real reader: the header reader's tables, a file positioned on the start block, uoff bytes to skip
+    kdf_reader *r = new kdf_reader();
+    r->kind = kdf_reader::BAM;
+    r->flag_off = flag_off; r->collapse = collapse != 0;
+    r->ref_names = hr->ref_names; r->ref_lens = hr->ref_lens; r->header_raw = hr->header_raw;
+    kdf_reader_close(hr);
+    r->fp = fopen(path, "rb");
+    if (!r->fp) { delete r; return rfail(nullptr, KDF_ERR_IO, "cannot open %s", path); }
+    setvbuf(r->fp, nullptr, _IOFBF, 1 << 20);
+    r->threads = std::min(threads, 64);
+    if (part + 1 < parts) r->range_hi = cut(part + 1);
+    if (!found) { r->range_done = true; r->eof = true; *out = r; return KDF_OK; }      // an empty range
+    if (fseeko(r->fp, (off_t)blk_off, SEEK_SET) != 0) { kdf_reader_close(r); return rfail(nullptr, KDF_ERR_IO, "%s: seek failed", path); }
+    if (r->threads > 1) r->pool.reset(new BgzfPool(r->fp, r->threads));
+    bool er = false;
+    if (!bam_need(r, uoff, &er) && er) { g_host_err = std::string(path) + ": " + r->err; kdf_reader_close(r); return KDF_ERR_IO; }
+    r->inpos = std::min(uoff, r->inbuf.size());
+    // (a start that already lies past this range's end -- a range smaller than a run -- is an empty range: the walk's
+    // first record is in the end zone and opens a run)
     *out = r;
     return KDF_OK;
 }

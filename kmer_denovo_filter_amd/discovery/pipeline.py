@@ -20,13 +20,15 @@ import time
 
 import numpy as np
 
-from .. import devkeys, jf_io
+from .. import devkeys, dist_env, jf_io
 from .._native import KdfError
 from ..core.jellyfish_wrappers import (
+    _device,
     _engine_capacity_hint,
     _estimate_jf_hash_size,
     _format_elapsed,
     _format_file_size,
+    _merge_filter_counts,
     _stream_bam,
 )
 from ..engine import KmerEngine
@@ -35,7 +37,7 @@ from ..kmer_fasta import read_kmer_fasta_keys, remove_with_sidecar, write_kmer_f
 logger = logging.getLogger(__name__)
 
 
-def _child_key_parts(child_bam, device=0):
+def _child_key_parts(child_bam, device=0, world=1):
     """Slices of the key space for the child count: ``KDF_KEY_PARTS`` when set, else from the BAM size and
     the free HBM.  Rule of thumb (30x human WGS: ~0.6 BAM bytes per base, ~0.14 distinct 31-mers per base with
     0.5 % errors): distinct ~ 0.23 x BAM bytes, table bytes ~ 12 x distinct / 0.6 ~ 4.6 x BAM bytes; the table
@@ -47,7 +49,7 @@ def _child_key_parts(child_bam, device=0):
     from .. import _native
     free, total = c_uint64(0), c_uint64(0)
     _native.check(_native.load().kdf_device_memory(device, byref(free), byref(total)))
-    need = 4.6 * os.path.getsize(child_bam)
+    need = 4.6 * os.path.getsize(child_bam) / max(1, world)      # (several ranks: every rank holds its share of the keys twice -- local + owned)
     return max(1, int(-(-need // max(1.0, 0.7 * free.value))))
 
 
@@ -64,9 +66,21 @@ def _extract_child_kmers_discovery(child_bam, ref_fasta, kmer_size, min_child_co
     # A 30x human sample has ~10^10 distinct 31-mers (sequencing errors included): more than one table in
     # 288 GB of HBM holds.  KDF_KEY_PARTS = P counts the key space in P slices, one pass over the BAM each
     # (Jellyfish's answer to the same problem is to spill and merge hash files, jellyfish_wrappers.py:335-366).
-    parts = _child_key_parts(child_bam)
+    world, rank, host = dist_env.world_rank()
+    parts = _child_key_parts(child_bam, _device(), world)
+    owner_eng = merger = None
     try:
-        with KmerEngine(kmer_size, capacity_hint=max(1, _engine_capacity_hint(jf_hash_size, child_bam) // parts)) as eng:
+        local_hint = max(1, _engine_capacity_hint(jf_hash_size, child_bam) // parts)
+        with KmerEngine(kmer_size, capacity_hint=max(1, local_hint // world) if world > 1 else local_hint, device=_device()) as eng:
+            if world > 1:
+                # one process per GPU: every rank counts its ranges of the BAM into a local table, one owner-partitioned
+                # exchange moves each (k-mer, count) pair to the rank that owns the k-mer, the owner sums -- and `dump -L`
+                # runs on the owners' tables (distributed.OwnerPartitionedCount; SURVEY.md section 8e "full count stage")
+                import torch
+                from ..distributed import EngineOps, OwnerPartitionedCount
+                dev = torch.device("cuda", eng.device)
+                owner_eng = KmerEngine(kmer_size, capacity_hint=max(1, local_hint // world), device=eng.device)
+                merger = OwnerPartitionedCount(EngineOps(eng, dev), device=dev, owner_ops=EngineOps(owner_eng, dev), stage_through_host=host)
             los, his = [], []
             dev_sets = []
             if parts > 1:
@@ -74,6 +88,8 @@ def _extract_child_kmers_discovery(child_bam, ref_fasta, kmer_size, min_child_co
             for part in range(parts):
                 if parts > 1:
                     eng.clear(); eng.set_option("key_part", part)
+                    if owner_eng is not None:
+                        owner_eng.clear()
                 _stream_bam(eng, child_bam, ref_fasta, threads, filtered=False)
                 cap, distinct, windows = eng.stats()
                 logger.info("Child k-mer counting complete (%s, slice %d of %d, %d windows, %d distinct, table %d slots)",
@@ -82,7 +98,12 @@ def _extract_child_kmers_discovery(child_bam, ref_fasta, kmer_size, min_child_co
                 dump_start = time.monotonic()
                 # the dump stays in HBM for the next stage (ascending keys: Jellyfish's dump order is not reproducible and
                 # nothing downstream relies on it, but the contract files are then the same bytes on every run)
-                dlo, dhi = devkeys.dump_ge(eng, min_child_count, eng.device)
+                if merger is None:
+                    dlo, dhi = devkeys.dump_ge(eng, min_child_count, eng.device)
+                else:
+                    merger.exchange()
+                    dlo, dhi = devkeys.dump_ge(owner_eng, min_child_count, eng.device)
+                    dlo, dhi = dist_env.all_gather_keys(dlo, dhi)           # every rank holds the whole candidate set
                 dev_sets.append((dlo, dhi))
                 lo, hi = devkeys.to_host(dlo, dhi)
                 los.append(lo); his.append(hi)
@@ -92,7 +113,19 @@ def _extract_child_kmers_discovery(child_bam, ref_fasta, kmer_size, min_child_co
                 dev_sets = [(torch.cat([d[0] for d in dev_sets]), torch.cat([d[1] for d in dev_sets]) if eng.wide else None)]
     except KdfError as e:
         raise RuntimeError(f"jellyfish count (child) failed: {e}") from e
-    n_candidates = write_kmer_fasta(child_candidates_fa, lo, hi, kmer_size)
+    finally:
+        if owner_eng is not None:
+            owner_eng.close()
+    if world > 1:                                                  # (rank order of the gathered sets is not key order)
+        order = np.lexsort((lo, hi))
+        lo, hi = lo[order], hi[order]
+        import torch
+        o = torch.from_numpy(order).to(dev_sets[0][0].device)
+        dev_sets = [(dev_sets[0][0][o].contiguous(), dev_sets[0][1][o].contiguous() if dev_sets[0][1] is not None else None)]
+    n_candidates = len(lo)
+    if rank == 0:
+        write_kmer_fasta(child_candidates_fa, lo, hi, kmer_size)
+    dist_env.barrier()                                             # the file exists (and has its final size) on every rank
     devkeys.register(child_candidates_fa, dev_sets[0][0], dev_sets[0][1], kmer_size)
     logger.info("Child k-mer dump complete (%s, %d candidates, FASTA: %s)",
                 _format_elapsed(time.monotonic() - dump_start), n_candidates,
@@ -117,10 +150,18 @@ def _subtract_reference_kmers(ref_jf, child_candidates_fa, tmpdir):
         if dev is None:
             lo, hi = read_kmer_fasta_keys(child_candidates_fa, k)
             dev = devkeys.from_host(lo, hi, k > 32) if len(lo) else None
+        world, rank, host = dist_env.world_rank()
         if dev is not None and dev[0].numel():
-            with KmerEngine(k, capacity_hint=max(jf_io.index_records(ref_jf), 1)) as eng:
-                jf_io.load_index_into(eng, ref_jf)               # memory-mapped, block by block (a human index is 30 GB)
-                keep = devkeys.query(eng, dev[0], dev[1], eng.device) == 0
+            with KmerEngine(k, capacity_hint=max(jf_io.index_records(ref_jf) // world, 1), device=_device()) as eng:
+                # memory-mapped, block by block (a human index is 30 GB); several ranks: every rank loads ITS share of the
+                # index's records and answers for all candidates, one all-reduce(sum) gives `jellyfish query`'s counts
+                jf_io.load_index_into(eng, ref_jf, part=rank, parts=world)
+                if world == 1:
+                    keep = devkeys.query(eng, dev[0], dev[1], eng.device) == 0
+                else:
+                    import torch
+                    from ..distributed import EngineOps, ShardedFilterCount
+                    keep = ShardedFilterCount(EngineOps(eng, torch.device("cuda", eng.device)), stage_through_host=host).merged_counts(dev[0], dev[1]) == 0
             dlo, dhi = dev[0][keep].contiguous(), (dev[1][keep].contiguous() if dev[1] is not None else None)
             lo, hi = devkeys.to_host(dlo, dhi)
         else:
@@ -128,11 +169,15 @@ def _subtract_reference_kmers(ref_jf, child_candidates_fa, tmpdir):
             lo = hi = np.zeros(0, np.uint64)
     except (KdfError, ValueError, OSError) as e:
         raise RuntimeError(f"jellyfish query (ref subtraction) failed: {e}") from e
-    n_non_ref = write_kmer_fasta(child_non_ref_fa, lo, hi, k)
+    n_non_ref = len(lo)
+    dist_env.barrier()                                             # every rank has read what it needs of the input file
+    if dist_env.is_root():
+        write_kmer_fasta(child_non_ref_fa, lo, hi, k)
+        remove_with_sidecar(child_candidates_fa)
+    dist_env.barrier()
     if dlo is not None:
         devkeys.register(child_non_ref_fa, dlo, dhi, k)
     devkeys.forget(child_candidates_fa)
-    remove_with_sidecar(child_candidates_fa)
     logger.info("Non-reference child k-mers after subtraction: %d", n_non_ref)
     return child_non_ref_fa, n_non_ref
 
@@ -149,12 +194,15 @@ def _count_parent_jellyfish(parent_bam, ref_fasta, kmer_fasta, kmer_size, parent
         lo, hi = read_kmer_fasta_keys(kmer_fasta, kmer_size)
         logger.info("  BAM stream -> MI355X count --if (k=%d, threads=%d, filter_kmers=%d)",
                     kmer_size, threads, len(lo))
-        with KmerEngine(kmer_size, capacity_hint=max(len(lo), 1)) as eng:
+        with KmerEngine(kmer_size, capacity_hint=max(len(lo), 1), device=_device()) as eng:
             eng.load_filter(lo, hi)
             _stream_bam(eng, parent_bam, ref_fasta, threads, filtered=True)
+            _merge_filter_counts(eng, lo, hi)                  # (several ranks: the sum of their shards' counts)
             flo, fhi, fcnt = eng.export_ge(0)
-        jf_io.write_index(jf_output, kmer_size, flo, fhi, fcnt,
-                          cmdline=["count", "-m", str(kmer_size), "-C", "--if", kmer_fasta, "-o", jf_output])
+        if dist_env.is_root():
+            jf_io.write_index(jf_output, kmer_size, flo, fhi, fcnt,
+                              cmdline=["count", "-m", str(kmer_size), "-C", "--if", kmer_fasta, "-o", jf_output])
+        dist_env.barrier()
     except (KdfError, ValueError, OSError) as e:
         raise RuntimeError(f"jellyfish count ({label}) failed: {e}") from e
     logger.info("  %s jellyfish counting complete (%s, index: %s)", label,
@@ -178,10 +226,11 @@ def _count_parent_on_device(parent_bam, ref_fasta, dlo, dhi, kmer_size, threads,
     logger.info("%s: scanning BAM (%s): %s", label, _format_file_size(parent_bam), parent_bam)
     scan_start = time.monotonic()
     logger.info("  BAM stream -> MI355X count --if (k=%d, threads=%d, filter_kmers=%d)", kmer_size, threads, dlo.numel())
-    eng = KmerEngine(kmer_size, capacity_hint=max(int(dlo.numel()), 1))
+    eng = KmerEngine(kmer_size, capacity_hint=max(int(dlo.numel()), 1), device=_device())
     try:
         eng.load_filter_dev(dlo.data_ptr(), dhi.data_ptr() if dhi is not None else None, int(dlo.numel()))
         _stream_bam(eng, parent_bam, ref_fasta, threads, filtered=True)
+        _merge_filter_counts(eng, None, None, dlo, dhi)        # (several ranks: one all-reduce of the per-key counts)
     except Exception:
         eng.close()
         raise
@@ -227,7 +276,9 @@ def _filter_parents_discovery(mother_bam, father_bam, ref_fasta, child_non_ref_f
 
     dlo, dhi = one_parent(mother_bam, "Mother", dlo, dhi)
     after_mother_fa = os.path.join(tmpdir, "after_mother.fa")
-    n_surviving = write_kmer_fasta(after_mother_fa, *devkeys.to_host(dlo, dhi), kmer_size)
+    n_surviving = int(dlo.numel())
+    if dist_env.is_root():                                         # (the contract files are written once; every rank holds the same sets)
+        write_kmer_fasta(after_mother_fa, *devkeys.to_host(dlo, dhi), kmer_size)
     logger.info("Mother: %d / %d non-ref k-mers found (count > %d), %d surviving",
                 n_input - n_surviving, n_input, parent_max_count, n_surviving)
     if n_surviving == 0:
@@ -235,8 +286,11 @@ def _filter_parents_discovery(mother_bam, father_bam, ref_fasta, child_non_ref_f
 
     dlo, dhi = one_parent(father_bam, "Father", dlo, dhi)
     proband_unique_fa = os.path.join(tmpdir, "proband_unique.fa")
-    n_proband = write_kmer_fasta(proband_unique_fa, *devkeys.to_host(dlo, dhi), kmer_size)
-    remove_with_sidecar(after_mother_fa)
+    n_proband = int(dlo.numel())
+    if dist_env.is_root():
+        write_kmer_fasta(proband_unique_fa, *devkeys.to_host(dlo, dhi), kmer_size)
+        remove_with_sidecar(after_mother_fa)
+    dist_env.barrier()
     logger.info("Father: %d / %d surviving k-mers found (count > %d), %d proband-unique",
                 n_surviving - n_proband, n_surviving, parent_max_count, n_proband)
     logger.info("Proband-unique k-mers (absent from both parents): %d / %d", n_proband, n_input)

@@ -160,6 +160,11 @@ class KmerEngine:
                                              c_void_p(d_counts) if d_counts else None, int(n)))
         return self
 
+    def set_counts_dev(self, d_lo: int, d_hi: Optional[int], d_counts: int, n: int):
+        """The count of every listed (stored) key becomes d_counts[i] (``kdf_set_counts_dev``)."""
+        self._ck(self._lib.kdf_set_counts_dev(self._h, c_void_p(d_lo), c_void_p(d_hi) if d_hi else None, c_void_p(d_counts), int(n)))
+        return self
+
     def add_pairs_multi_dev(self, segments):
         """Sum several device-resident segments of (lo ptr, hi ptr or None, counts ptr, n) into the table in ONE call
         (the owner's half of the multi-GPU merge, ``kdf_add_pairs_multi_dev``)."""

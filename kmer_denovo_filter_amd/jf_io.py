@@ -88,7 +88,7 @@ def _decode(data, kb: int, cb: int):
     return lo, hi, counts
 
 
-def iter_index(path: str, expect_k: Optional[int] = None, chunk_records: int = 1 << 24):
+def iter_index(path: str, expect_k: Optional[int] = None, chunk_records: int = 1 << 24, part: int = 0, parts: int = 1):
     """Yield (k, lo, hi or None, counts) blocks of at most ``chunk_records`` records.  The file is memory-mapped and
     decoded block by block, so a whole-genome index (2.5e9 records, 30 GB on disk) needs ~0.5 GB of host memory at a
     time where `read_index` would need every record decoded at once (Jellyfish itself mmaps the file,
@@ -97,23 +97,26 @@ def iter_index(path: str, expect_k: Optional[int] = None, chunk_records: int = 1
     if n == 0:
         return
     mm = np.memmap(path, dtype=rec, mode="r", offset=off, shape=(n,))
+    first, last = n * part // parts, n * (part + 1) // parts      # this part's records (one rank's share of the index)
     try:
-        for a in range(0, n, chunk_records):
-            lo, hi, counts = _decode(mm[a:a + chunk_records], kb, cb)
+        for a in range(first, last, chunk_records):
+            lo, hi, counts = _decode(mm[a:min(a + chunk_records, last)], kb, cb)
             yield k, lo, hi, counts
     finally:
         del mm
 
 
-def load_index_into(engine, path: str, expect_k: Optional[int] = None, chunk_records: int = 1 << 24) -> int:
+def load_index_into(engine, path: str, expect_k: Optional[int] = None, chunk_records: int = 1 << 24,
+                    part: int = 0, parts: int = 1) -> int:
     """Stream an index into ``engine``'s table (`jellyfish query`'s view of the .jf): the table is sized once for the
-    record count, then the blocks are added one by one.  Returns the number of records."""
+    record count, then the blocks are added one by one.  ``part`` of ``parts``: only that share of the records (the
+    index sharded over the ranks of a multi-GPU job).  Returns the number of records of the whole index."""
     k, _, _, _, _, n = _index_layout(path, expect_k)
     if k != engine.k:
         raise ValueError(f"{path}: index has k={k}, the engine counts k={engine.k}")
     if n:
-        engine.reserve(n)
-    for _, lo, hi, counts in iter_index(path, expect_k, chunk_records):
+        engine.reserve(max(1, n // parts + 1))
+    for _, lo, hi, counts in iter_index(path, expect_k, chunk_records, part, parts):
         engine.add_pairs(lo, hi, counts)
     return n
 

@@ -289,70 +289,85 @@ def _pinned_ring(ring: int, max_bases: int) -> PinnedBatches:
     return pb
 
 
-def stream_batches_overlapped(engine, reader, filtered: bool, ring: int = 3) -> int:
-    """Count every batch of ``reader`` on ``engine`` as a three-stage pipeline: a reader thread decodes batch i + 2
-    into a pinned buffer (the native reader releases the GIL), the copy stream uploads batch i + 1, the engine
-    counts batch i.  Returns the number of reads."""
+def stream_batches_overlapped(engine, readers, filtered: bool, ring: int = 0) -> int:
+    """Count every batch of ``readers`` (one reader, or several readers of disjoint ranges of one file:
+    ``bam_reader(part=, parts=)``) on ``engine`` as a three-stage pipeline: one reader thread PER READER decodes batches
+    into pinned buffers (the native reader releases the GIL; inflate, chunking and parsing of the ranges run side by
+    side), the copy stream uploads batch i + 1, the engine counts batch i.  Batches arrive in any order: counting does
+    not care.  Returns the number of reads."""
     import queue
     import threading
+    if not isinstance(readers, (list, tuple)):
+        readers = [readers]
     n_reads = 0
-    pinned = _pinned_ring(ring, reader.max_bases)
-    if True:
-        free, ready = queue.Queue(), queue.Queue()
-        for i in range(ring):
-            free.put(i)
-        stop = threading.Event()
+    ring = ring or len(readers) + 2
+    pinned = _pinned_ring(ring, readers[0].max_bases)
+    free, ready = queue.Queue(), queue.Queue()
+    for i in range(ring):
+        free.put(i)
+    stop = threading.Event()
 
-        def produce():
-            try:
-                while not stop.is_set():
-                    i = free.get()
-                    if i is None:
-                        break
-                    st = reader.next_into(*pinned.batches[i])
-                    if st is None:
-                        break
-                    ready.put((i, st))
-                ready.put(None)
-            except BaseException as ex:  # noqa: BLE001 -- handed to the consumer
-                ready.put(ex)
-
-        th = threading.Thread(target=produce, name="kdf-reader", daemon=True)
-        th.start()
-        pending = None                                   # (slot, buffer) uploaded, not yet counted
-        slot = 0
+    def produce(reader):
         try:
-            while True:
-                item = ready.get()
-                if item is None:
+            while not stop.is_set():
+                i = free.get()
+                if i is None:
+                    free.put(None)                           # (pass the stop token on to the other producers)
                     break
-                if isinstance(item, BaseException):
-                    raise item
-                i, st = item
-                engine.upload_async(slot, st)            # returns at once: the buffer is pinned
-                n_reads += st.n_reads
-                if pending is not None:
-                    engine.count_uploaded(pending[0], filtered)
-                    free.put(pending[1])                 # count_uploaded waited (on the HOST) for this buffer's copy
-                pending = (slot, i)
-                slot ^= 1
+                st = reader.next_into(*pinned.batches[i])
+                if st is None:
+                    free.put(i)                              # unused: back to the ring
+                    break
+                ready.put((i, st))
+            ready.put(None)
+        except BaseException as ex:  # noqa: BLE001 -- handed to the consumer
+            ready.put(ex)
+
+    threads = [threading.Thread(target=produce, args=(rd,), name="kdf-reader", daemon=True) for rd in readers]
+    for th in threads:
+        th.start()
+    pending = None                                           # (slot, buffer) uploaded, not yet counted
+    slot = 0
+    live = len(threads)
+    try:
+        while live:
+            item = ready.get()
+            if item is None:
+                live -= 1
+                continue
+            if isinstance(item, BaseException):
+                raise item
+            i, st = item
+            engine.upload_async(slot, st)                    # returns at once: the buffer is pinned
+            n_reads += st.n_reads
             if pending is not None:
                 engine.count_uploaded(pending[0], filtered)
-                pending = None
-        finally:
-            stop.set()
-            free.put(None)
-            th.join()                                    # the native reader call always returns; never close the reader under it
-            engine.synchronize()                         # no copy may still read a pinned buffer the next caller will fill
+                free.put(pending[1])                         # count_uploaded waited (on the HOST) for this buffer's copy
+            pending = (slot, i)
+            slot ^= 1
+        if pending is not None:
+            engine.count_uploaded(pending[0], filtered)
+            pending = None
+    finally:
+        stop.set()
+        free.put(None)
+        for th in threads:
+            th.join()                                        # the native reader call always returns; never close a reader under it
+        engine.synchronize()                                 # no copy may still read a pinned buffer the next caller will fill
     return n_reads
 
 
 def bam_reader(path: str, flag_off: int = FLAG_OFF_SAMTOOLS_FASTA, collapse: bool = True,
                max_bases: int = 1 << 26, max_reads: int = 1 << 20, threads: int = 1,
-               want_meta: bool = False, want_aux: bool = False) -> _Reader:
-    """``samtools fasta -F flag_off`` as an iterator of ReadStream batches."""
+               want_meta: bool = False, want_aux: bool = False, part: int = 0, parts: int = 1) -> _Reader:
+    """``samtools fasta -F flag_off`` as an iterator of ReadStream batches.  ``part`` of ``parts``: one BGZF range of
+    the file, cut on record (QNAME-run) boundaries -- the parts together are the whole file, each record once
+    (``kdf_bam_open_range``: the shard of one rank, or of one reader pipeline inside a process)."""
     h = c_void_p()
-    rc = _native.load().kdf_bam_open(path.encode(), flag_off, 1 if collapse else 0, threads, byref(h))
+    if parts > 1:
+        rc = _native.load().kdf_bam_open_range(path.encode(), flag_off, 1 if collapse else 0, threads, int(part), int(parts), byref(h))
+    else:
+        rc = _native.load().kdf_bam_open(path.encode(), flag_off, 1 if collapse else 0, threads, byref(h))
     _native.check_reader(rc, None)
     return _Reader(h, max_bases, max_reads, want_meta, want_aux, is_bam=True)
 

@@ -207,3 +207,32 @@ def test_cram_is_recognised_by_its_magic_bytes(tmp_path):
         with bam_reader(str(p)) as rd:
             next(iter(rd))
     assert "CRAM" in str(ei.value) and "samtools view -b" in str(ei.value)
+
+
+@pytest.mark.parametrize("collapse,flag_off", [(True, 0xD00), (False, 0x500)])
+def test_bgzf_ranges_together_are_the_whole_file(tmp_path, collapse, flag_off):
+    """kdf_bam_open_range: the parts 0 .. n - 1 of a BAM, read one after the other, yield exactly the records the
+    plain reader yields -- same sequences, same order -- for any number of parts (more parts than BGZF blocks: the
+    surplus ones are empty), with 1 or several threads per part, and no QNAME run is split at a cut (the synthetic file
+    has runs of three records, dropped records inside runs, and cuts fall inside runs)."""
+    from helpers import write_bam
+    rng = np.random.default_rng(31)
+    B = np.frombuffer(b"ACGTN", np.uint8)
+    reads = []
+    for i in range(30_000):
+        flag = [0x41, 0x81, 0x941][i % 3] if i % 7 else 0x141
+        seq = B[rng.integers(0, 5, int(rng.integers(1, 160)), dtype=np.int64).clip(0, 4)].tobytes().decode()
+        reads.append({"name": f"read{i // 3}", "seq": seq, "pos": i, "flag": flag, "aux": b"NMC\x03", "qual": bool(i % 4)})
+    syn = str(tmp_path / "runs.bam")
+    write_bam(syn, [("chr1", 1_000_000), ("chr2", 5000)], reads)
+    for path in (os.path.join(GIAB, "HG002_child.bam"), syn):
+        whole = _drain(path, flag_off=flag_off, collapse=collapse, threads=1, max_bases=1 << 22)[0]
+        assert len(whole) > 5000
+        for parts, threads in ((2, 1), (3, 4), (7, 1), (16, 3), (61, 1), (400, 1)):
+            got, sizes = [], []
+            for p in range(parts):
+                seqs = _drain(path, flag_off=flag_off, collapse=collapse, threads=threads, max_bases=1 << 20, part=p, parts=parts)[0]
+                got += seqs; sizes.append(len(seqs))
+            assert got == whole, (path, parts, threads, sizes)
+            if parts <= 16:
+                assert min(sizes) > 0, (parts, sizes)                      # every range of a file this size holds records
