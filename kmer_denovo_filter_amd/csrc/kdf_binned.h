@@ -729,28 +729,33 @@ __device__ __forceinline__ void kb_probe_narrow(uint64_t *tlo, uint32_t *tcnt, u
     failed = true;
 }
 
-// wide keys, one ATTEMPT from slot `sl`: 0 done, 1 bucket full, 2 blocked by a slot another lane is publishing.
-// The caller retries blocked keys under a wave-uniform loop: no lane ever waits inside a divergent loop.
+// Wide keys in the LDS slice: a slot is CLAIMED BY ITS HASH WORD -- one 64-bit CAS EMPTY -> h on tlo, as for narrow keys;
+// the winner then stores the key's high word into thi (which reads EMPTY until then).  A prober that finds its h compares
+// thi: equal = the key; EMPTY = claimed a moment ago, not yet published (BLOCKED: retried under a wave-uniform loop, no
+// lane ever waits inside a divergent loop); anything else = another key with the same 64-bit hash (2^-64 per pair): probe on.
+// (Rounds 1-2 claimed by `hi | PENDING` on thi and published lo, final hi: every slot comparison took two words and a flag
+// test, and the bucket kernel issued more scalar than vector instructions -- 3.9 G against 3.6 G per pass at k = 63.)
+// A key whose h IS the empty marker cannot be stored this way: its bucket is handed to the replay path (direct kernels).
+// One ATTEMPT from slot `sl`: 0 done, 1 bucket full, 2 blocked.
 template <int MODE>
 __device__ __forceinline__ int kb_probe_wide_once(uint64_t *tlo, uint64_t *thi, uint32_t *tcnt, uint32_t bmask,
                                                   uint64_t klo, uint64_t khi, uint32_t sl, uint32_t &claimed) {
     for (uint32_t n = 0; n <= bmask; ++n) {
-        uint64_t chi = __hip_atomic_load(&thi[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (chi == KDF_EMPTY && MODE == KB_MODE_INSERT) {
-            chi = atomicCAS((unsigned long long *)&thi[sl], KDF_EMPTY, khi | KDF_PENDING);
-            if (chi == KDF_EMPTY) {
-                __hip_atomic_store(&tlo[sl], klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(&thi[sl], khi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint64_t c = __hip_atomic_load(&tlo[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (c == KDF_EMPTY) {
+            if (MODE != KB_MODE_INSERT) return 0;                 // FILTERED: absent
+            c = atomicCAS((unsigned long long *)&tlo[sl], KDF_EMPTY, klo);
+            if (c == KDF_EMPTY) {
+                __hip_atomic_store(&thi[sl], khi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 claimed++;
                 atomicAdd(&tcnt[sl], 1u);
                 return 0;
             }
         }
-        if (chi == KDF_EMPTY) return 0;                           // FILTERED: absent
-        if ((chi & ~KDF_PENDING) == khi) {
-            if (chi & KDF_PENDING) return 2;
-            const uint64_t clo = __hip_atomic_load(&tlo[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (clo == klo) { atomicAdd(&tcnt[sl], 1u); return 0; }
+        if (c == klo) {
+            const uint64_t h2 = __hip_atomic_load(&thi[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (h2 == khi) { atomicAdd(&tcnt[sl], 1u); return 0; }
+            if (h2 == KDF_EMPTY) return 2;                        // claimed, not yet published
         }
         sl = (sl + 1) & bmask;
     }
@@ -811,10 +816,16 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
     const uint32_t c = (uint32_t)(pb >> plan.c2), f = (uint32_t)(pb & ((1u << plan.c2) - 1));
     const uint64_t slot0 = bucket << plan.bucket_bits;        // first slot of the bucket in HBM
     if (threadIdx.x == 0) { sh_failed = 0; sh_claimed = 0; }
+    bool failed = false;
     if (table_nonempty) {
         for (uint32_t i = threadIdx.x; i < B; i += CT) {
             tlo[i] = t.lo[slot0 + i];
-            if constexpr (KW == 2) thi[i] = t.hi[slot0 + i];
+            if constexpr (KW == 2) {
+                thi[i] = t.hi[slot0 + i];
+                // (a stored key whose hash word equals the empty marker -- put there by the direct kernels, 2^-64 per key --
+                // cannot live in a slice whose emptiness is read off the hash word: the bucket goes to the replay path)
+                if ((tlo[i] == KDF_EMPTY) != (thi[i] == KDF_EMPTY)) failed = true;
+            }
             tcnt[i] = t.cnt[slot0 + i];
         }
     } else {
@@ -836,7 +847,6 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
     const uint32_t bmask = B - 1;
     const uint32_t hsh_r = 64 - plan.log2cap;                 // home slot = h >> hsh_r (binned tables have no hash_shift)
     uint32_t claimed = 0;
-    bool failed = false;
     // Runs of this bucket: one per chunk of its coarse bin and pending pass.  Their bounds are
     // fetched by all threads at once (one global latency, not one per run) and
     // laid out in LDS as a flat work list; threads then take entries round
@@ -1039,64 +1049,57 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
                 wq_n = 0;
             }
           } else {
-            // Two-word keys, same scheme.  The hi words of the lookahead slots are read BEFORE their lo
-            // words (LDS serves a wave's instructions in order and a claimer writes lo before the final
-            // hi), so a slot whose hi reads as the key's hi without PENDING has its lo in place.  A slot
-            // seen PENDING with this hi may become this key: it goes to the queue.  The straight-line
-            // code never waits; the queue is drained under the wave-uniform retry loop.
+            // Two-word keys, same scheme on the HASH words (claim protocol: kb_probe_wide_once above): two slots of tlo read
+            // up front, the first that holds h or is empty resolved in straight-line code -- CAS where it read empty, the
+            // winner publishes its high word, a lane that found h compares the high word -- and whatever needs more (both
+            // slots taken by other keys, a lost CAS, a slot not yet published) goes to the wave queue, drained under the
+            // wave-uniform retry loop.
             constexpr int G = 2;
 #pragma unroll
             for (int q0 = 0; q0 < EPB; q0 += G) {
                 if (e0 + q0 * CT >= total) break;
-                uint64_t chi[G][KB_C_LA], clo[G][KB_C_LA]; uint32_t sl0[G]; bool td[G];
+                uint64_t cur[G][KB_C_LA]; uint32_t sl0[G]; bool td[G];
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     const uint32_t ei = wbase + QSTEP * (q0 + g);
                     const uint64_t home = bklo[q0 + g] >> hsh_r;                  // the entry's first word is the hash
                     td[g] = ei < total && !(plan.sub_bits && (home >> plan.bucket_bits) != bucket);
+                    if (td[g] && bklo[q0 + g] == KDF_EMPTY) { failed = true; td[g] = false; }   // (2^-64: the replay path stores it)
                     sl0[g] = (uint32_t)home & bmask;
 #pragma unroll
-                    for (int i = 0; i < KB_C_LA; ++i) chi[g][i] = __hip_atomic_load(&thi[(sl0[g] + i) & bmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    for (int i = 0; i < KB_C_LA; ++i) cur[g][i] = __hip_atomic_load(&tlo[(sl0[g] + i) & bmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
 #pragma unroll
                 for (int g = 0; g < G; ++g)
 #pragma unroll
-                    for (int i = 0; i < KB_C_LA; ++i) asm volatile("" : "+v"(chi[g][i]) :: "memory");      // hi words first ...
-#pragma unroll
-                for (int g = 0; g < G; ++g)
-#pragma unroll
-                    for (int i = 0; i < KB_C_LA; ++i) clo[g][i] = __hip_atomic_load(&tlo[(sl0[g] + i) & bmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-                for (int g = 0; g < G; ++g)
-#pragma unroll
-                    for (int i = 0; i < KB_C_LA; ++i) asm volatile("" : "+v"(clo[g][i]) :: "memory");      // ... then the lo words
+                    for (int i = 0; i < KB_C_LA; ++i) asm volatile("" : "+v"(cur[g][i]) :: "memory");
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     const uint64_t klo = bklo[q0 + g], khi = bkhi[q0 + g];
-                    uint32_t r = KB_C_LA; int kind = 0;                      // 1 the key, 2 empty, 3 this hi, still PENDING
+                    uint32_t r = KB_C_LA; bool found = false;                // found: the slot holds h
 #pragma unroll
                     for (int i = KB_C_LA - 1; i >= 0; --i) {
-                        const uint64_t h = chi[g][i];
-                        const bool same = (h & ~KDF_PENDING) == khi;
-                        const bool m = h == khi && clo[g][i] == klo, e = h == KDF_EMPTY, pd = same && (h & KDF_PENDING);
-                        if (m || e || pd) { r = (uint32_t)i; kind = m ? 1 : (e ? 2 : 3); }
+                        const bool m = cur[g][i] == klo, e = cur[g][i] == KDF_EMPTY;
+                        if (m || e) { r = (uint32_t)i; found = m; }
                     }
                     if (!__any(td[g])) continue;
                     uint32_t sl = (sl0[g] + r) & bmask;
-                    bool hit = td[g] && kind == 1;
-                    bool more = td[g] && (r == KB_C_LA || kind == 3);
-                    if (td[g] && kind == 2) {
+                    bool hit = false;
+                    bool more = td[g] && r == KB_C_LA;
+                    if (td[g] && !more && !found) {                          // read empty
                         if constexpr (MODE == KB_MODE_INSERT) {
-                            const uint64_t old = atomicCAS((unsigned long long *)&thi[sl], KDF_EMPTY, khi | KDF_PENDING);
+                            const uint64_t old = atomicCAS((unsigned long long *)&tlo[sl], KDF_EMPTY, klo);
                             if (old == KDF_EMPTY) {
-                                __hip_atomic_store(&tlo[sl], klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                __hip_atomic_store(&thi[sl], khi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_store(&thi[sl], khi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 claimed++; hit = true;
-                            } else {
-                                more = true;                                 // taken meanwhile: by this key (same hi) or by another
-                                if ((old & ~KDF_PENDING) != khi) sl = (sl + 1) & bmask;
-                            }
+                            } else if (old == klo) found = true;             // taken meanwhile by this hash: compare the high word below
+                            else { more = true; sl = (sl + 1) & bmask; }
                         }                                                    // FILTERED: absent
+                    }
+                    if (td[g] && found) {
+                        const uint64_t h2 = __hip_atomic_load(&thi[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (h2 == khi) hit = true;
+                        else { more = true; if (h2 != KDF_EMPTY) sl = (sl + 1) & bmask; }   // not yet published: the queue looks again; another key: probe on
                     }
                     kb_count_hits<VAR == 2>(tcnt, sl, hit);
                     const unsigned long long mk = __ballot(more);

@@ -4,7 +4,7 @@
 Corrections (MI355X_MICROARCH.md, "HBM"): the counters are in KiB; on gfx950
 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read,
 so it is doubled; WRITE_SIZE is taken as is.  Our loads are 8 B per lane rather
-than the calibrated 16 B, so the fine-sort kernel -- which reads and writes
+than the calibrated 16 B, so the piece-sort kernel -- which reads and writes
 exactly 8 B per entry -- is printed as a calibration point next to its known
 byte count.
 """
@@ -42,10 +42,8 @@ pipeline = cfg.get("count_path", "binned")
 wide = cfg["k"] > 32
 # prefixes of the kernels of one count pass, per pipeline
 names = {
-    "binned": ("kb_hist1_kernel<", "kb_colscan_kernel", "kb_scan1_kernel", "kb_scatter1_kernel<", "kb_scatter2_kernel<", "kb_poolscan_kernel",
-               "kb_chunklist_kernel", "kb_finesort_kernel<", "kb_finesort2_kernel<", "kb_bucket_kernel<"),
-    "superkmer": ("sk_extract_kernel<", "sk_binscan_kernel", "sk_chunklist_kernel", "sk_finesort_kernel", "sk_bucket_kernel<",
-                  "sk_spill_insert_kernel", "sk_weight_records_kernel", "sk_assign_kernel"),
+    "binned": ("kb_slabsort_kernel<", "kb_groupsum_kernel", "kb_binscan_kernel<", "kb_binfirst_kernel", "kb_piecesort_kernel<",
+               "kb_piecesort_more_kernel<", "kb_bucket_kernel<", "kb_heavy_slice_kernel", "kb_heavy_combine_kernel", "kb_replay_kernel<"),
 }.get(pipeline, ("kdf_stream_kernel<",))
 rows, total = [], 0.0
 for k in sorted(set(fetch) | set(write)):
@@ -64,7 +62,7 @@ summary = {
     "hbm_bytes_per_window": total / n_entries,
     "kernels": rows,
     "calibration": {
-        "kernel": "kb_finesort_kernel<%d>" % (2 if wide else 1), "known_read_bytes": n_entries * (16 if wide else 8),
+        "kernel": "kb_piecesort_kernel<%d>" % (2 if wide else 1), "known_read_bytes": n_entries * (16 if wide else 8),
         "known_write_bytes": n_entries * (16 if wide else 8),
         "note": "binned pipeline: known = one entry each way (plus < 1 % offset tables)",
     },
@@ -76,5 +74,5 @@ if len(sys.argv) > 3 and sys.argv[3] == "latest":          # the default bench w
     json.dump(summary, open("profiles/traffic_latest.json", "w"), indent=1)
 for r in rows:
     print(f"{r['kernel'][:36]:38s} x{r['dispatches']:<3d} read {r['read_bytes']/1e9:8.3f} GB  write {r['write_bytes']/1e9:8.3f} GB")
-print("known finesort: read %.3f GB write %.3f GB" % (n_entries * 8 / 1e9, n_entries * 8 / 1e9))
+print("known piecesort: read %.3f GB write %.3f GB" % (n_entries * (16 if wide else 8) / 1e9, n_entries * (16 if wide else 8) / 1e9))
 print("pass total %.2f GB = %.1f B/window (%s pipeline, k=%d)" % (total / 1e9, total / n_entries, pipeline, cfg["k"]))
