@@ -188,6 +188,8 @@ def run_count(args, world, rank, local_rank):
     eng = KmerEngine(k, capacity_hint=local_hint, device=local_rank)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_option("force_path", {"auto": 0, "direct": 1, "binned": 2}[args.path])
+    if os.environ.get("KDF_DEBUG_FLAGS"):                  # experiments only (A/B runs of kernel variants)
+        eng.set_option("debug_flags", int(os.environ["KDF_DEBUG_FLAGS"]))
     merger = None
     if world > 1:
         from kmer_denovo_filter_amd.distributed import EngineOps, OwnerPartitionedCount
