@@ -21,7 +21,7 @@ while time.time() - t0 < budget:
     reads = rand_reads(rng, n, max(1, k - 3), int(rng.integers(k + 1, 400)), n_frac=float(rng.choice([0, 0.002, 0.05])), genome=genome)
     if rng.random() < 0.3:
         reads += ["A" * int(rng.integers(k, 500))] * int(rng.integers(1, 60)) + ["ACGT" * 100] * int(rng.integers(0, 20))
-    path = int(rng.choice([1, 2])); flags = int(rng.choice([0, 8])); hint = int(rng.choice([1 << 8, 1 << 12, 1 << 16, 1 << 20]))
+    path = int(rng.choice([0, 1, 2, 2])); flags = int(rng.choice([0, 4096])); hint = int(rng.choice([1 << 8, 1 << 12, 1 << 16, 1 << 20]))
     maxpos = int(rng.choice([1 << 31, 4096, 65536]))
     st = ReadStream.from_strings(reads)
     t = O.OracleTable(k, 1 << 12).count_reads(reads)

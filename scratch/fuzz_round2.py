@@ -1,5 +1,6 @@
-"""Randomised parity of the ROUND-2 code paths against the oracle (GPU box): super-k-mer pipeline, cell / pool scatter,
-the membership sieve for count --if, owner tables (hash_shift) and the multi-segment merge (LDS bucket merge when the
+"""Randomised parity of the ROUND-2 / ROUND-3 code paths against the oracle (GPU box): deferred flushes over streamed
+batches, the pending stream of small batches, the membership sieve for count --if, owner tables (hash_shift) and the
+multi-segment merge (LDS bucket merge when the
 segments are in hash order, atomic fallback otherwise).  Everything is compared bit for bit."""
 import sys, time
 import numpy as np
