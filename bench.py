@@ -389,7 +389,8 @@ def run_parent_filter(args, world, rank, local_rank):
     n_filter = int(filt.numel())
     del cand, in_ref, gs
     # the parent's read shard of this rank (reads are independent units: SURVEY.md section 8e)
-    per_rank = reads // world
+    # --scaling strong: one parent's reads are a fixed job dealt out to the ranks; weak: every rank its own `reads` reads
+    per_rank = reads // world if args.scaling == "strong" else reads
     parent = synth_stream(per_rank, L, genome_len, seed=20260421 + 1000 * rank, device=dev, genome=ref)
     torch.cuda.synchronize()
     if rank == 0:
@@ -465,12 +466,13 @@ def run_parent_filter(args, world, rank, local_rank):
         "unit": "Gk-mer/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,     # (one parent's reads are a fixed job dealt out to the ranks)
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "u64" if k <= 32 else "u128",
         "data": "synthetic" if not args.rehearse_one_gpu else "synthetic (REHEARSAL: all ranks on one GPU over gloo; not a measurement)",
         "config": {
             "workload": f"parent_filter (BASELINE configs[2] substitute, SURVEY 8d item 3): synthetic {genome_len} bp genome, "
-                        f"{reads} x {L} bp parent reads (30x) sharded over the ranks, k={k}, count --if against the child's "
+                        f"{per_rank} x {L} bp parent reads per rank ({'a fixed job of ' + str(reads) + ' sharded over the ranks' if args.scaling == 'strong' else 'weak scaling'}), "
+                        f"k={k}, count --if against the child's "
                         f"{n_filter} non-reference k-mers (0.1 % planted SNVs, count >= 3), per-key counts + <= 0 threshold",
             "filter_keys": n_filter, "parent_reads": reads, "windows_rank0": windows, "survivors": survivors,
             "count_path": feng.last_count_path(),

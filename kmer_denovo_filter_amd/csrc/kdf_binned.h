@@ -69,6 +69,14 @@
 static_assert(KB_C_EPB_N % 4 == 0 && KB_C_EPB_W % 4 == 0, "kernel C resolves entries four at a time");
 static_assert(KB_C_THREADS % 256 == 0 && KB_C_THREADS <= 1024 && KB_C_THREADS_W % 256 == 0 && KB_C_THREADS_W <= KB_C_THREADS, "whole waves on every SIMD");
 #define KB_C_CT(KW) ((KW) == 2 ? KB_C_THREADS_W : KB_C_THREADS)
+// BIG: tables of 2^32 slots and more have buckets of twice the slots (kdf_engine.hip: table_alloc) -- 96 / 80 KB of LDS per
+// bucket, one workgroup of 1024 threads per CU.  Beyond 2^19 buckets the partition (10 + 9 bits) leaves sub-buckets to
+// kernel C, which reads every run once per sub-bucket; twice the bucket halves that.  Measured: 8 bench batches into 2^32
+// slots, C 9.05 -> 8.44 ms per batch; 64 small batches into 2^33 slots 38 -> 41.7 Gk-mer/s; but a 2^31-slot table is
+// better off with two 4096-slot workgroups per CU and 10 + 9 bits (77 against 70 Gk-mer/s), hence the threshold.
+#define KB_C_CT_BIG 1024
+#define KB_C_CTB(KW, BIG) ((BIG) ? KB_C_CT_BIG : KB_C_CT(KW))
+#define KB_BB_SMALL(KW) ((KW) == 1 ? 12u : 11u)         // bucket bits of tables below the threshold
 #define KB_C_RUNS    256                 // runs (chunks of the coarse bin) staged per round
 
 // Threads of the slab kernel: 1024 x 16 windows = 16 K-entry slabs (132 KB of LDS, one workgroup per CU).  512 (8 K slabs,
@@ -76,6 +84,14 @@ static_assert(KB_C_THREADS % 256 == 0 && KB_C_THREADS <= 1024 && KB_C_THREADS_W 
 // gathers are runs of SLAB / bins entries: 128 bytes instead of 256.
 #ifndef KB_A_THREADS
 #define KB_A_THREADS 1024
+#endif
+#ifndef KB_A_SCAN
+#define KB_A_SCAN 0                      // 1: every wave scans its own 64 bins (measured: slab kernel 3.17 against 3.13 ms); 0: one wave scans them all
+#endif
+#ifndef KB_A_B4
+#define KB_A_B4 1                        // 1: a fourth barrier per slab after the write-out.  Not needed for correctness, but without it the
+                                         // slab kernel is SLOWER (3.24 against 3.13 ms, same box): waves that run ahead into the next slab's
+                                         // ranking atomics slow the write-out of the others down
 #endif
 template <int KW> struct KbCfg;
 // WPT windows per thread of the slab kernel; SLAB stream positions (= entries at most) per slab; CHUNK = capacity of a piece
@@ -325,6 +341,7 @@ __global__ __launch_bounds__(KB_A_THREADS) void kb_slabsort_kernel(
 #pragma unroll
         for (int u = 0; u < WPT; ++u) br[u] |= atomicAdd(&hist[br[u] >> 16], 1u) & 0xFFFFu;
         kb_lds_barrier();                                               // B1: all ranks taken
+#if KB_A_SCAN == 0
         if (threadIdx.x < 64) {
             // exclusive scan of hist[0..nb) by one wave: each lane owns a contiguous strip
             const int per = (nb + 63) >> 6;                             // 1..16
@@ -338,6 +355,24 @@ __global__ __launch_bounds__(KB_A_THREADS) void kb_slabsort_kernel(
             for (int i = 0; i < per; ++i) if (b0 + i < nb) { offs[b0 + i] = run; run += hist[b0 + i]; }
             if (threadIdx.x == 63) offs[nb] = inc;                      // the slab's valid windows
         }
+#else
+        // exclusive scan of hist[0..nb): wave w owns the bins [64 w, 64 w + 64); what lies below them is summed by the
+        // wave itself (lane l adds hist[l + 64 j], j < w: independent reads, one wave reduction) -- no extra barrier, and
+        // no wave walks 16 dependent LDS round trips while fifteen wait (the one-wave scan: ~0.5 us per slab)
+        if ((int)threadIdx.x < ((nb + 63) & ~63)) {                     // whole waves
+            const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+            uint32_t below = 0;
+            for (int j = 0; j < w; ++j) below += hist[l + 64 * j];      // (w is wave-uniform)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
+            const uint32_t v = (int)threadIdx.x < nb ? hist[threadIdx.x] : 0u;
+            uint32_t inc = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if (l >= o) inc += t; }
+            if ((int)threadIdx.x < nb) offs[threadIdx.x] = below + inc - v;
+            if ((int)threadIdx.x == nb - 1) offs[nb] = below + inc;   // the slab's valid windows
+        }
+#endif
         kb_lds_barrier();                                               // B2: offsets ready
         {
             // invalid windows land on the trash slot (offs[DUMMY] = SLAB, rank masked off)
@@ -377,7 +412,9 @@ __global__ __launch_bounds__(KB_A_THREADS) void kb_slabsort_kernel(
                 for (uint32_t i = threadIdx.x; i < (nv + 1) / 2; i += NT) dst[i] = src[i];      // (SLAB is even: the odd tail stays inside the slab's block)
             }
         }
+#if KB_A_B4
         kb_lds_barrier();                                               // B4: image free (stores still draining)
+#endif
         win = nxt;
     }
 }
@@ -782,14 +819,15 @@ __device__ __forceinline__ void kb_probe_wide_wave(uint64_t *tlo, uint64_t *thi,
 #ifndef KB_C_LA
 #define KB_C_LA    2                   // slots of the probe sequence read up front
 #endif
-#define KB_C_QCAPK(KW) (((KW) == 2 ? KB_C_WQ_W : 128) * (KB_C_CT(KW) / 64))   // queue entries per workgroup
-#define KB_C_LDS(KW, BB) (((size_t)8 * (KW) + 4) * ((size_t)1 << (BB)) + (2 + 32 + KB_C_RUNS) * 4 + (size_t)KB_C_RUNS * 8 + ((KW) == 2 ? (size_t)KB_C_RUNS * 4 : 0) \
-                          + KB_C_QCAPK(KW) * ((KW) == 2 ? 18 : 10) + 16 + (KB_C_RUNS + 4) * 4 + KB_RI_LDS_BYTES)
-template <int KW, int MODE, int VAR>
-__global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_C_WPE, KB_C_WPE))) void kb_bucket_kernel(
+#define KB_C_QCAPT(KW, CT_) (((KW) == 2 ? KB_C_WQ_W : 128) * ((CT_) / 64))   // queue entries per workgroup
+#define KB_C_LDS_T(KW, BB, CT_) (((size_t)8 * (KW) + 4) * ((size_t)1 << (BB)) + (2 + 32 + KB_C_RUNS) * 4 + (size_t)KB_C_RUNS * 8 + ((KW) == 2 ? (size_t)KB_C_RUNS * 4 : 0) \
+                          + KB_C_QCAPT(KW, CT_) * ((KW) == 2 ? 18 : 10) + 16 + (KB_C_RUNS + 4) * 4 + KB_RI_LDS_BYTES)
+#define KB_C_LDS(KW, BB) KB_C_LDS_T(KW, BB, KB_C_CTB(KW, (BB) > KB_BB_SMALL(KW)))
+template <int KW, int MODE, int VAR, bool BIG = false>
+__global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_eu(BIG ? 4 : KB_C_WPE, BIG ? 4 : KB_C_WPE))) void kb_bucket_kernel(
     KbPlan plan, KbScratch s, KdfTable t, KdfCtl *ctl, int table_nonempty)
 {
-    constexpr uint32_t CT = KB_C_CT(KW), QCAP = KB_C_QCAPK(KW);      // threads and queue entries per workgroup
+    constexpr uint32_t CT = KB_C_CTB(KW, BIG), QCAP = KB_C_QCAPT(KW, CT);      // threads and queue entries per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t B = 1u << plan.bucket_bits;
     uint64_t *tlo = (uint64_t *)smem;                         // [B]
@@ -859,7 +897,7 @@ __global__ __launch_bounds__(KB_C_CT(KW)) __attribute__((amdgpu_waves_per_eu(KB_
         if constexpr (VAR == 2 && KW == 1 && MODE == KB_MODE_INSERT) {
             // A heavy bucket (a few keys of enormous multiplicity) is not for ONE workgroup: it is left untouched here, as
             // a failed bucket would be, and KB_HV_SLICES workgroups share its runs afterwards (kb_heavy_slice_kernel).
-            if (rb == 0 && total > KB_C_HEAVY && s.hv_ctr && plan.sub_bits == 0 && plan.bucket_bits == 12) {   // (the host launches the heavy kernels under the same conditions)
+            if (rb == 0 && total > KB_C_HEAVY && s.hv_ctr && plan.sub_bits == 0) {   // (the host launches the heavy kernels under the same conditions)
                 if (threadIdx.x == 0) {
                     const uint32_t idx = atomicAdd(&s.hv_ctr[0], 1u);
                     sh_failed = idx;                          // (borrowed as a broadcast word; restored below)

@@ -480,6 +480,7 @@ struct kdf_engine {
     uint64_t opt_binned_bytes_per_position = 70;     // ... and so does a flush of fewer than table_bytes / 70 positions (use_binned)
     uint64_t opt_binned_max_positions = 1ull << 31;  // longer streams are partitioned in several passes
     uint32_t opt_binned_filtered_min_log2cap = 23;   // count --if goes binned from 2^23 slots (measured crossover)
+    uint32_t opt_big_bucket_log2cap = 32;            // tables from 2^32 slots on have buckets of twice the slots (KDF_BIG_BUCKET_LOG2CAP / option big_bucket_log2cap)
     uint64_t opt_merge_min_pairs = KDF_MERGE_MIN_PAIRS;   // below this many pairs a merge goes straight to the atomic insert (tests lower it)
     uint32_t opt_hash_shift = 0;                     // KdfTable::hshift of the tables this engine creates (owner tables)
     int opt_force_path = 0;                          // 0 auto, 1 direct, 2 binned, 4 sieve only (count --if)
@@ -498,6 +499,7 @@ struct kdf_engine {
     uint32_t merge_flag_host = 0;
     int last_merge_path = 0;                         // 0 none yet, 1 LDS bucket merge launched, 2 plain atomic insert
     int opt_sieve_bits = 0;                          // sieve bits per filter key (0: 32 up to 2^20 keys, 16 beyond)
+    bool merge_attrs_set[3] = {false, false, false};  // km_merge_kernel's LDS limit raised (big buckets)
     bool attrs_set[4] = {false, false, false, false};   // hipFuncSetAttribute done (per key width)
     int last_path = 0;                               // count path of the last count call: 0 direct, 1 binned, 3 sieve
     uint64_t *sieve = nullptr;                       // blocked Bloom filter over the filter keys (count --if)
@@ -548,7 +550,8 @@ static int table_alloc(kdf_engine *h, uint32_t log2cap, KdfTable &t, bool clear 
     const uint64_t cap = 1ull << log2cap;
     t = KdfTable{};
     t.log2cap = log2cap;
-    t.bucket_bits = std::min<uint32_t>(log2cap, h->kw == 1 ? 12 : 11);   // 48 / 40 KB of LDS per bucket
+    // 48 / 40 KB of LDS per bucket; tables of 2^big_bucket_log2cap slots and more: twice that (kdf_binned.h: KB_C_CT_BIG)
+    t.bucket_bits = std::min<uint32_t>(log2cap, KB_BB_SMALL(h->kw) + (log2cap >= h->opt_big_bucket_log2cap ? 1u : 0u));
     t.hshift = h->opt_hash_shift;
     {
         hipError_t e = hipMalloc((void **)&t.lo, cap * 8);
@@ -628,7 +631,16 @@ static int by_width(kdf_engine *h, F &&f) { return h->kw == 1 ? f(std::integral_
 static int table_rehash(kdf_engine *h, uint32_t new_log2) {
     // (the window counter lives on the device between synchronisations: pending partition passes have added to it)
     { int rc0 = ctl_sync(h, nullptr); if (rc0) return rc0; }
-    { int rc0 = materialize(h); if (rc0) return rc0; }
+    if (h->lazy_empty || h->distinct == 0) {              // nothing to carry over: a new table (a lazily cleared one stays so)
+        KdfTable nt0;
+        int rc0 = table_alloc(h, new_log2, nt0, !h->lazy_empty);
+        if (rc0) return rc0;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        table_free(h->t);
+        h->t = nt0; h->t.key_parts = h->opt_key_parts; h->t.key_part = h->opt_key_part;
+        h->cap = 1ull << new_log2;
+        return KDF_OK;
+    }
     KdfTable nt;
     int rc = table_alloc(h, new_log2, nt);
     if (rc) { table_free(nt); return rc; }
@@ -636,13 +648,17 @@ static int table_rehash(kdf_engine *h, uint32_t new_log2) {
     const uint64_t windows = h->windows;
     rc = ctl_reset(h, false);
     if (rc) { table_free(nt); return rc; }
-    const unsigned blocks = (unsigned)((old_cap + 255) / 256);
-    if (h->kw == 1)
-        hipLaunchKernelGGL(kdf_insert_keys_kernel<1>, dim3(blocks), dim3(256), 0, h->stream,
-                           (const uint64_t *)h->t.lo, (const uint64_t *)nullptr, (const uint32_t *)h->t.cnt, old_cap, nt, h->ctl, 1, 1);
-    else
-        hipLaunchKernelGGL(kdf_insert_keys_kernel<2>, dim3(blocks), dim3(256), 0, h->stream,
-                           (const uint64_t *)h->t.lo, (const uint64_t *)h->t.hi, (const uint32_t *)h->t.cnt, old_cap, nt, h->ctl, 1, 1);
+    // (a launch holds fewer than 2^32 threads: tables of 2^32 slots and more go in pieces of 2^30 slots)
+    for (uint64_t off = 0; off < old_cap; off += 1ull << 30) {
+        const uint64_t n = std::min<uint64_t>(1ull << 30, old_cap - off);
+        const unsigned blocks = (unsigned)((n + 255) / 256);
+        if (h->kw == 1)
+            hipLaunchKernelGGL(kdf_insert_keys_kernel<1>, dim3(blocks), dim3(256), 0, h->stream,
+                               (const uint64_t *)h->t.lo + off, (const uint64_t *)nullptr, (const uint32_t *)h->t.cnt + off, n, nt, h->ctl, 1, 1);
+        else
+            hipLaunchKernelGGL(kdf_insert_keys_kernel<2>, dim3(blocks), dim3(256), 0, h->stream,
+                               (const uint64_t *)h->t.lo + off, (const uint64_t *)h->t.hi + off, (const uint32_t *)h->t.cnt + off, n, nt, h->ctl, 1, 1);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { table_free(nt); return fail(h, KDF_ERR_HIP, "rehash launch failed: %s", hipGetErrorString(e)); }
     bool full = false;
@@ -753,9 +769,12 @@ static int kb_set_lds_attrs(kdf_engine *h, size_t a, size_t b, size_t c, size_t 
     HIPCHK(h, hipFuncSetAttribute((const void *)(kb_slabsort_kernel<KW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a));
     HIPCHK(h, hipFuncSetAttribute((const void *)kb_piecesort_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b));
     HIPCHK(h, hipFuncSetAttribute((const void *)kb_piecesort_more_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b));
+    const size_t cbig = KB_C_LDS(KW, KB_BB_SMALL(KW) + 1);
 #define KB_SETV(V) \
-    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_INSERT, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c)); \
-    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_FILTERED, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c));
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_INSERT, V, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c)); \
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_FILTERED, V, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c)); \
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_INSERT, V, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cbig)); \
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_FILTERED, V, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cbig));
     KB_SETV(1)
     KB_SETV(2)
 #undef KB_SETV
@@ -777,7 +796,7 @@ static int kb_scratch(kdf_engine *h, KbScratch &s) {
         HIPCHK(h, hipMalloc((void **)&h->kb_pass, sizeof(KbPass) * KB_MAX_PASS));
     }
     if (h->kw == 1 && !h->kb_heavy) {                             // heavy buckets of skewed flushes (kb_heavy_slice_kernel): ~100 MB, once
-        const size_t pairs = (size_t)KB_HV_MAX * KB_HV_SLICES << 12;
+        const size_t pairs = (size_t)KB_HV_MAX * KB_HV_SLICES << (KB_BB_SMALL(1) + 1);       // (room for the buckets of big tables)
         HIPCHK(h, hipMalloc((void **)&h->kb_heavy, pairs * 12 + (4 + 3 * KB_HV_MAX) * 4));
         HIPCHK(h, hipMemsetAsync((char *)h->kb_heavy + pairs * 12, 0, (4 + 3 * KB_HV_MAX) * 4, h->stream));
     }
@@ -785,7 +804,7 @@ static int kb_scratch(kdf_engine *h, KbScratch &s) {
     s.totals = h->kb_small;
     s.pass = h->kb_pass;
     if (h->kw == 1 && h->kb_heavy) {
-        const size_t pairs = (size_t)KB_HV_MAX * KB_HV_SLICES << 12;
+        const size_t pairs = (size_t)KB_HV_MAX * KB_HV_SLICES << (KB_BB_SMALL(1) + 1);
         s.hv_key = (uint64_t *)h->kb_heavy; s.hv_cnt = (uint32_t *)(s.hv_key + pairs);
         s.hv_ctr = s.hv_cnt + pairs; s.hv_bucket = s.hv_ctr + 4; s.hv_n = s.hv_bucket + KB_HV_MAX; s.hv_failed = s.hv_n + KB_HV_MAX;
     }
@@ -865,8 +884,8 @@ static int kb_partition(kdf_engine *h, const uint64_t *d_packed, const uint64_t 
     const size_t lds_a = (size_t)(SLAB + 2) * 8 * KW + (size_t)(2 * (nb1 + 32)) * 4;
     const size_t lds_b = (size_t)CHUNK * 8 * KW + (size_t)(2 * KB_F + 32) * 4 + (size_t)KB_G_MAX * 12 + 32;
     if (!h->attrs_set[KW]) {                                   // once per engine
-        const size_t lds_c = KB_C_LDS(KW, (KW == 1 ? 12 : 11));
-        if ((rc = kb_set_lds_attrs<KW>(h, lds_a, lds_b, lds_c, ((size_t)12 << 12) + KB_RI_LDS_BYTES))) return rc;
+        const size_t lds_c = KB_C_LDS(KW, KB_BB_SMALL(KW));
+        if ((rc = kb_set_lds_attrs<KW>(h, lds_a, lds_b, lds_c, ((size_t)12 << (KB_BB_SMALL(1) + 1)) + KB_RI_LDS_BYTES))) return rc;
         h->attrs_set[KW] = true;
     }
     // the pass's own buffers: slab-sorted entries, offset rows, planning arrays (reused by the next pass: stream order)
@@ -983,14 +1002,16 @@ static int kb_flush_ring(kdf_engine *h) {
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, h->stream);
         hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, h->stream); sev.push_back(e);
     }
-    const bool heavy = skewed && h->kw == 1 && !filtered && s.hv_ctr && plan.bucket_bits == 12 && plan.sub_bits == 0;
+    const bool heavy = skewed && h->kw == 1 && !filtered && s.hv_ctr && plan.sub_bits == 0;
     if (heavy) {
         HIPCHK(h, hipMemsetAsync(s.hv_ctr, 0, (4 + 3 * KB_HV_MAX) * 4, h->stream));
     }
     by_width(h, [&](auto KWc) {
         constexpr int KW = decltype(KWc)::value;
         const size_t lds_c = KB_C_LDS(KW, plan.bucket_bits);
-#define KB_LV(M, V) hipLaunchKernelGGL((kb_bucket_kernel<KW, M, V>), dim3((unsigned)nb_table), dim3(KB_C_CT(KW)), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty)
+        const bool big = plan.bucket_bits > KB_BB_SMALL(KW);
+#define KB_LV(M, V) do { if (big) hipLaunchKernelGGL((kb_bucket_kernel<KW, M, V, true>), dim3((unsigned)nb_table), dim3(KB_C_CT_BIG), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty); \
+                         else hipLaunchKernelGGL((kb_bucket_kernel<KW, M, V, false>), dim3((unsigned)nb_table), dim3(KB_C_CT(KW)), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty); } while (0)
         if (filtered) { if (skewed) KB_LV(KB_MODE_FILTERED, 2); else KB_LV(KB_MODE_FILTERED, 1); }
         else { if (skewed) KB_LV(KB_MODE_INSERT, 2); else KB_LV(KB_MODE_INSERT, 1); }
 #undef KB_LV
@@ -1259,6 +1280,7 @@ int kdf_create(int device, int k, uint64_t capacity_hint, kdf_engine **out) {
     if ((e = hipHostMalloc((void **)&h->h_out4, 32)) != hipSuccess) { h->err = hipGetErrorString(e); return bail(KDF_ERR_NOMEM); }
     int rc = ctl_reset(h, false);
     if (rc) return bail(rc);
+    if (const char *ev = getenv("KDF_BIG_BUCKET_LOG2CAP")) { const int v = atoi(ev); if (v >= 10 && v <= 64) h->opt_big_bucket_log2cap = (uint32_t)v; }
     rc = table_alloc(h, cap_log2_for(capacity_hint), h->t);
     if (rc) return bail(rc);
     h->cap = 1ull << h->t.log2cap;
@@ -1610,6 +1632,16 @@ static int add_pairs_multi(kdf_engine *h, uint32_t nseg, const uint64_t *const *
         const dim3 pg((unsigned)((nmax + 255) / 256), m);
         const size_t lds_bytes = ((size_t)8 * h->kw + 4) << h->t.bucket_bits;
         const bool fresh = h->lazy_empty;            // the kernel writes every bucket: it IS the deferred clear
+        if (lds_bytes > 65536 && !h->merge_attrs_set[h->kw]) {       // big buckets: past the default limit of dynamic LDS
+            int rca = by_width(h, [&](auto KWc) {
+                constexpr int KW = decltype(KWc)::value;
+                HIPCHK(h, hipFuncSetAttribute((const void *)(km_merge_kernel<KW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                HIPCHK(h, hipFuncSetAttribute((const void *)(km_merge_kernel<KW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                return KDF_OK;
+            });
+            if (rca) return rca;
+            h->merge_attrs_set[h->kw] = true;
+        }
         by_width(h, [&](auto KWc) {
             constexpr int KW = decltype(KWc)::value;
             hipLaunchKernelGGL(km_bounds_kernel<KW>, pg, dim3(256), 0, h->stream, h->t, sg, nb, first, last, flag);
@@ -2077,6 +2109,12 @@ int kdf_set_option(kdf_engine *h, const char *name, int64_t value) {
         h->opt_binned_max_positions = (uint64_t)value / KDF_TILE * KDF_TILE;      // passes start on tile boundaries
     }
     else if (n == "binned_filtered_min_log2cap") h->opt_binned_filtered_min_log2cap = (uint32_t)value;
+    else if (n == "big_bucket_log2cap") {
+        if (value < 10 || value > 64) return fail(h, KDF_ERR_INVALID, "big_bucket_log2cap must be 10..64");
+        h->opt_big_bucket_log2cap = (uint32_t)value;
+        const uint32_t bb = std::min<uint32_t>(h->t.log2cap, KB_BB_SMALL(h->kw) + (h->t.log2cap >= h->opt_big_bucket_log2cap ? 1u : 0u));
+        if (bb != h->t.bucket_bits) { int rc = table_rehash(h, h->t.log2cap); if (rc) return rc; }     // same slots, other buckets
+    }
     else if (n == "force_path") h->opt_force_path = (int)value;
     else if (n == "merge_min_pairs") h->opt_merge_min_pairs = (uint64_t)value;
     else if (n == "hash_shift") {

@@ -81,7 +81,11 @@ def round2_case(O, rng, scale, tag0):
 
     skewvar = 4096 if rng.random() < 0.5 else 0              # kernel C's skew instantiation (wave-aggregated count adds), forced
 
+    bigb = (31, 10, 14)[(len(reads) + k) % 3]                # tables from 2^bigb slots on take the big-bucket instantiation of kernel C
+                                                             # (not drawn from rng: the cases of earlier rounds stay what they were)
+
     def opts(e, p=path):
+        e.set_option("big_bucket_log2cap", bigb)
         e.set_option("force_path", p); e.set_option("binned_max_positions", maxpos); e.set_option("debug_flags", skewvar)
         e.set_option("defer", defer); e.set_option("l1_positions", l1); e.set_option("l1_direct_positions", 4 * l1)
         e.set_option("binned_min_positions", int(rng.choice([1 << 10, 1 << 22])))
@@ -137,6 +141,7 @@ def round2_case(O, rng, scale, tag0):
         segs.append((tl.data_ptr(), th.data_ptr() if wide else None, tc.data_ptr(), len(plo)))
     torch.cuda.synchronize()
     with KmerEngine(k, capacity_hint=int(rng.choice([1 << 8, 1 << 16]))) as own:
+        own.set_option("big_bucket_log2cap", bigb)
         own.set_option("hash_shift", own_shift)
         own.set_option("merge_min_pairs", int(rng.choice([1, 1, 1 << 16])))
         pre = rng.random() < 0.3 and len(parts[0]) > 0      # a live table: the first part is counted in directly, not merged
@@ -161,7 +166,7 @@ def round2_case(O, rng, scale, tag0):
         ot = O.OracleTable(k, 1 << 12).load_filter(lo[sel], hi[sel]).count_reads_filtered(other)
         fp = int(rng.choice([0, 1, 2, 4, 4])); sb = int(rng.choice([0, 8, 16, 32]))
         with KmerEngine(k, capacity_hint=hint) as e:
-            e.set_option("sieve_bits", sb)
+            e.set_option("sieve_bits", sb); e.set_option("big_bucket_log2cap", bigb)
             e.load_filter(lo[sel], hi[sel] if wide else None)
             e.set_option("force_path", fp); e.set_option("binned_max_positions", maxpos)
             e.count_filtered(ReadStream.from_strings(other))

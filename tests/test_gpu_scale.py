@@ -253,16 +253,22 @@ def test_path_choice_follows_batch_and_table_size():
         assert torch.equal(dumps[name][0], dumps["auto"][0]) and torch.equal(dumps[name][1], dumps["auto"][1])
 
 
-def test_widest_partition_geometry_binned_equals_direct():
-    """A table of 2^32 slots takes the widest partition the pipeline has (1024 coarse bins, 1024 fine bins, groups of
+@pytest.mark.parametrize("bigb", [31, 64])
+def test_widest_partition_geometry_binned_equals_direct(bigb):
+    """A table of 2^32 slots takes the widest partition the pipeline has (1024 coarse bins, 512 fine bins, groups of
     1024 slabs -- one run per thread of the piece kernel, the case in which round 3's first strong-scaling job read past
-    its run table); 300 k reads in two passes, deferred, against the direct path on a small table."""
+    its run table); 300 k reads in two passes, deferred, against the direct path on a small table.  With 8192-slot
+    buckets (bigb = 31; the default takes them from 2^32 slots on) that resolves the table; with 4096-slot buckets (bigb = 64) kernel C
+    takes two sub-buckets per partition bucket."""
     import torch
     from kmer_denovo_filter_amd import KmerEngine
     ds = _dev_stream(300_000, seed=9)
     dumps = []
     for hint, force in ((1 << 31, 2), (1 << 24, 1)):
         with KmerEngine(31, capacity_hint=hint) as e:
+            e.set_option("big_bucket_log2cap", bigb)
+            if force == 2:
+                assert e.get_stat("bucket_bits") == (13 if bigb == 31 else 12)
             e.set_option("force_path", force)
             third = ds.n_bases // 3 // 64 * 64
             e.count_dev(ds.packed.data_ptr(), ds.invalid.data_ptr(), third)
@@ -277,3 +283,62 @@ def test_widest_partition_geometry_binned_equals_direct():
             dumps.append((lo[:n], cnt[:n], windows))
     assert dumps[0][2] == dumps[1][2]
     assert torch.equal(dumps[0][0], dumps[1][0]) and torch.equal(dumps[0][1], dumps[1][1])
+
+
+@pytest.mark.parametrize("k", [31, 63])
+def test_big_buckets_binned_equals_direct_and_merge(k):
+    """Tables from 2^big_bucket_log2cap slots on have buckets of twice the slots (8192 narrow / 4096 wide: one
+    1024-thread workgroup of kernel C per CU).  Forced here on a mid-size table: the binned path into big buckets in two
+    deferred passes, a growth in between (rehash into big buckets), the LDS bucket merge of its dump into a second
+    big-bucket table, and the same reads through the direct path into ordinary buckets must give the same sorted dump."""
+    import torch
+    from kmer_denovo_filter_amd import KmerEngine
+    ds = _dev_stream(300_000, seed=21)
+    wide = k > 32
+
+    def dump(e):
+        _, distinct, windows = e.stats()
+        lo = torch.empty(distinct, dtype=torch.int64, device="cuda:0"); cnt = torch.empty(distinct, dtype=torch.int32, device="cuda:0")
+        hi = torch.empty(distinct, dtype=torch.int64, device="cuda:0") if wide else None
+        n = e.export_ge_dev(0, lo.data_ptr(), hi.data_ptr() if wide else None, cnt.data_ptr(), distinct, sorted_=True); e.synchronize()
+        assert n == distinct
+        return lo, hi, cnt, windows
+
+    half = ds.n_bases // 2 // 64 * 64
+    with KmerEngine(k, capacity_hint=1 << 22) as e:                 # too small for the sample: it grows under load
+        e.set_option("big_bucket_log2cap", 12)
+        assert e.get_stat("bucket_bits") == (13 if not wide else 12)
+        e.set_option("force_path", 2)
+        e.count_dev(ds.packed.data_ptr(), ds.invalid.data_ptr(), half)
+        e.flush()
+        e.count_dev(ds.packed.data_ptr() + half // 4, ds.invalid.data_ptr() + half // 8, ds.n_bases - half)
+        big = dump(e)
+        assert e.get_stat("bucket_bits") == (13 if not wide else 12) and e.get_stat("binned_passes") >= 2
+        # the dump in ascending order of the stored form (what the owner-ordered dump of a big table is): the LDS bucket merge
+        # takes segments grouped by table bucket
+        nd = big[0].numel()
+        x = big[0].clone()
+        if wide:
+            x ^= (big[1] << 37) | ((big[1] >> 27) & ((1 << 37) - 1))
+        hsh = (x ^ ((x >> 32) & 0xFFFFFFFF)) * (0x9FB21C651E98DF25 - (1 << 64))
+        order = torch.argsort(hsh ^ (-(1 << 63)))               # unsigned order
+        plo, pcnt = big[0][order].contiguous(), big[2][order].contiguous()
+        phi = big[1][order].contiguous() if wide else None
+        torch.cuda.synchronize()
+        with KmerEngine(k, capacity_hint=1 << 12) as own:
+            own.set_option("big_bucket_log2cap", 12); own.set_option("merge_min_pairs", 1)
+            own.clear()
+            own.add_pairs_multi_dev([(plo.data_ptr(), phi.data_ptr() if wide else None, pcnt.data_ptr(), nd)])
+            own.synchronize()
+            assert own.get_stat("last_merge_path") == 1 and own.get_stat("bucket_bits") == (13 if not wide else 12)
+            merged = dump(own)
+    with KmerEngine(k, capacity_hint=1 << 24) as d:
+        d.set_option("force_path", 1)
+        d.count_dev(ds.packed.data_ptr(), ds.invalid.data_ptr(), half)
+        d.count_dev(ds.packed.data_ptr() + half // 4, ds.invalid.data_ptr() + half // 8, ds.n_bases - half)
+        ref = dump(d)
+    for got in (big, merged):
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2])
+        if wide:
+            assert torch.equal(got[1], ref[1])
+    assert big[3] == ref[3]
