@@ -155,6 +155,7 @@ struct KbScratch {
     uint32_t *hv_bucket, *hv_n, *hv_failed;   // [KB_HV_MAX]
     uint64_t *hv_key;               // [KB_HV_MAX][KB_HV_SLICES << 12]
     uint32_t *hv_cnt;
+    uint64_t *trash;                // [32] words nobody reads: where the pipelined piece sort stores when it has nothing to store
 };
 #ifndef KB_HV_MAX
 #define KB_HV_MAX    64u                             // heavy buckets split per flush (further ones are processed the ordinary way)
@@ -170,6 +171,17 @@ __device__ __forceinline__ uint32_t kb_coarse(const KbPlan &p, uint64_t h) {
 __device__ __forceinline__ uint32_t kb_fine(const KbPlan &p, uint64_t h) {
     return p.c2 ? (uint32_t)((h >> (64 - p.c1 - p.c2)) & ((1u << p.c2) - 1)) : 0u;
 }
+
+// Phase timing of a kernel, for variant builds only (-DKB_TIMING; scratch/build_variant.sh): thread 0 of every workgroup
+// adds the cycles since its last stamp to trash[8 + n] (read back through kdf_get_stat "trashN").
+#ifdef KB_TIMING
+#define KB_T_INIT unsigned long long kb_t_prev = __builtin_readcyclecounter()
+#define KB_T(tr, n) do { if (threadIdx.x == 0) { const unsigned long long kb_t_now = __builtin_readcyclecounter(); \
+                          atomicAdd((unsigned long long *)&(tr)[8 + (n)], kb_t_now - kb_t_prev); kb_t_prev = kb_t_now; } } while (0)
+#else
+#define KB_T_INIT do {} while (0)
+#define KB_T(tr, n) do {} while (0)
+#endif
 
 // block-wide exclusive scan of n <= KB_THREADS uint32 values held one per
 // thread (threads >= n pass 0); returns the exclusive prefix, total via *tot.
@@ -315,9 +327,11 @@ __global__ __launch_bounds__(KB_A_THREADS) void kb_slabsort_kernel(
     if (slab0 * TILES_PER_SLAB >= n_tiles) return;                     // uniform
     KbWindows<KW> win;
     win.load(packed, invalid, slab0 * TILES_PER_SLAB + threadIdx.x / TPT, n_tiles, threadIdx.x % TPT, k);
+    KB_T_INIT;
     for (uint32_t sl = 0; sl < slabs_per_wg; ++sl) {
         const uint64_t slab = slab0 + sl;
         if (slab * TILES_PER_SLAB >= n_tiles) break;                  // uniform
+        KB_T(s.trash, 18);                                               // (loop turn-around: B4, win = nxt)
         KbWindows<KW> nxt;
         {
             // prefetch of the next slab's words: loads only; (tile >= n_tiles handles "no next slab")
@@ -338,9 +352,16 @@ __global__ __launch_bounds__(KB_A_THREADS) void kb_slabsort_kernel(
             const uint32_t bin = ok ? kb_coarse(plan, hsh) : (uint32_t)DUMMY;
             br[u] = bin << 16;
         }
+        if (plan.dbg & 1024) {                                          // (ablation: counts without ranks -- WRONG results, timing only)
+#pragma unroll
+            for (int u = 0; u < WPT; ++u) atomicAdd(&hist[br[u] >> 16], 1u);
+        } else {
 #pragma unroll
         for (int u = 0; u < WPT; ++u) br[u] |= atomicAdd(&hist[br[u] >> 16], 1u) & 0xFFFFu;
+        }
+        KB_T(s.trash, 10);                                               // keys, bins, rank atomics issued
         kb_lds_barrier();                                               // B1: all ranks taken
+        KB_T(s.trash, 11);                                               // ... ranks back, barrier
 #if KB_A_SCAN == 0
         if (threadIdx.x < 64) {
             // exclusive scan of hist[0..nb) by one wave: each lane owns a contiguous strip
@@ -373,7 +394,9 @@ __global__ __launch_bounds__(KB_A_THREADS) void kb_slabsort_kernel(
             if ((int)threadIdx.x == nb - 1) offs[nb] = below + inc;   // the slab's valid windows
         }
 #endif
+        KB_T(s.trash, 12);                                               // scan (wave 0)
         kb_lds_barrier();                                               // B2: offsets ready
+        KB_T(s.trash, 13);
         {
             // invalid windows land on the trash slot (offs[DUMMY] = SLAB, rank masked off)
             uint32_t pos[WPT];
@@ -397,12 +420,15 @@ __global__ __launch_bounds__(KB_A_THREADS) void kb_slabsort_kernel(
         // retire the prefetched words of the next slab BEFORE the write-out is issued:
         // vmcnt retires in order, so a later wait for these loads would also wait
         // for every store issued in between
+        KB_T(s.trash, 14);                                               // scatter + offset row
         nxt.finish();
         asm volatile("" :: "v"(nxt.e[0]), "v"(nxt.e[1]), "v"(nxt.valid));
+        KB_T(s.trash, 15);                                               // next slab's words retired
         kb_lds_barrier();                                               // B3: sorted image complete
+        KB_T(s.trash, 16);
         {
             // ONE contiguous block per slab: 16 bytes per lane and step
-            const uint32_t nv = offs[nb];
+            const uint32_t nv = (plan.dbg & 256) ? 0u : offs[nb];          // (ablation 256: no write-out -- timing only)
             if constexpr (KW == 2) {
                 KbEnt2 *dst = (KbEnt2 *)s.tmp + slab * (uint64_t)SLAB;
                 for (uint32_t i = threadIdx.x; i < nv; i += NT) dst[i] = s2[i];
@@ -412,6 +438,10 @@ __global__ __launch_bounds__(KB_A_THREADS) void kb_slabsort_kernel(
                 for (uint32_t i = threadIdx.x; i < (nv + 1) / 2; i += NT) dst[i] = src[i];      // (SLAB is even: the odd tail stays inside the slab's block)
             }
         }
+        KB_T(s.trash, 17);                                               // write-out issued
+#ifdef KB_TIMING
+        if (threadIdx.x == 0) atomicAdd((unsigned long long *)&s.trash[8 + 19], 1ull);
+#endif
 #if KB_A_B4
         kb_lds_barrier();                                               // B4: image free (stores still draining)
 #endif
@@ -545,6 +575,7 @@ __device__ __forceinline__ void kb_sort_piece(const KbPlan &plan, const KbScratc
     const uint64_t row = P->row_base + P->binrow_first[c] + s.gpre_row[pair] + p;
     const unsigned long long dst0 = P->ent_base + P->binent_first[c] + s.gpre_ent[pair] + lo_;
     const int nf = 1 << plan.c2;
+    KB_T_INIT;
     for (int i = threadIdx.x; i < KB_F; i += KB_THREADS) hist[i] = 0;
     // the run of slab s0 + t in bin c
     const uint64_t s0 = (uint64_t)g * plan.group;
@@ -554,7 +585,9 @@ __device__ __forceinline__ void kb_sort_piece(const KbPlan &plan, const KbScratc
         const uint16_t *o = s.off + (s0 + threadIdx.x) * (uint64_t)(nb + 1) + c;
         o0 = o[0]; rl = (uint32_t)o[1] - o0;
     }
+    KB_T(s.trash, 0);                                                   // offsets loaded (the scan below waits for them)
     const uint32_t pre = kb_block_exscan(rl, wsum, nullptr);            // (barriers inside: hist is zeroed)
+    KB_T(s.trash, 1);
     if (threadIdx.x < ns) {
         rsrc[threadIdx.x] = (s0 + threadIdx.x) * (unsigned long long)SLAB + o0 - pre;
         rpre[threadIdx.x] = pre;
@@ -562,6 +595,7 @@ __device__ __forceinline__ void kb_sort_piece(const KbPlan &plan, const KbScratc
     if (threadIdx.x < 4) rpre[ns + threadIdx.x] = n_pair;               // padding: the run search below stops there (ns may equal the thread count)
     if (threadIdx.x == 0) { s.row_ent[row] = dst0; s.row_len[row] = len; }
     __syncthreads();
+    KB_T(s.trash, 2);
     uint64_t klo[EPT], khi[KW == 2 ? EPT : 1];
     uint32_t br[EPT];
     {
@@ -587,20 +621,27 @@ __device__ __forceinline__ void kb_sort_piece(const KbPlan &plan, const KbScratc
                     do { ++cr; cnx = rpre[cr + 1]; } while (e >= cnx);
                     cs = rsrc[cr];
                 }
-                if constexpr (KW == 2) { const KbEnt2 v = tmp2[cs + e]; klo[q] = v.lo; khi[q] = v.hi; }
-                else klo[q] = s.tmp[cs + e];
+                const unsigned long long src = (plan.dbg & 256) ? ((cs + e) & 0x3FFFFull) : cs + e;      // (ablation 256: gather from 2 MB, L2 resident -- timing only)
+                if constexpr (KW == 2) { const KbEnt2 v = tmp2[src]; klo[q] = v.lo; khi[q] = v.hi; }
+                else klo[q] = s.tmp[src];
             }
         }
+#ifdef KB_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        KB_T(s.trash, 3);                                               // gather: addresses, issue, arrival
+#endif
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
             const uint32_t i = wbase + 64 * q;
             if (i < len) {
                 const uint32_t f = kb_fine(plan, klo[q]);               // the entry is the hash
-                br[q] = (f << 16) | atomicAdd(&hist[f], 1u);
+                if (plan.dbg & 1024) { atomicAdd(&hist[f], 1u); br[q] = f << 16; }       // (ablation 1024: no ranks -- timing only)
+                else br[q] = (f << 16) | atomicAdd(&hist[f], 1u);
             }
         }
     }
     __syncthreads();
+    KB_T(s.trash, 4);                                                   // ranks
     {
         const uint32_t v = threadIdx.x < nf ? hist[threadIdx.x] : 0;
         const uint32_t ex = kb_block_exscan(v, wsum, nullptr);
@@ -611,6 +652,7 @@ __device__ __forceinline__ void kb_sort_piece(const KbPlan &plan, const KbScratc
         if (threadIdx.x == 0) s.chunk_off[row * plan.off_stride + nf] = len;
     }
     __syncthreads();
+    KB_T(s.trash, 5);                                                   // scan
     {
         const uint32_t wbase = (threadIdx.x >> 6) * (64 * EPT) + (threadIdx.x & 63);
 #pragma unroll
@@ -623,6 +665,8 @@ __device__ __forceinline__ void kb_sort_piece(const KbPlan &plan, const KbScratc
         }
     }
     __syncthreads();
+    KB_T(s.trash, 6);                                                   // scatter
+    if (plan.dbg & 512) return;                                         // (ablation 512: no write-out -- timing only)
     if constexpr (KW == 2) {
         // the sorted piece is stored as piece-local structure of arrays -- len h words, then len hi
         // words, in the same 16 * len bytes -- because kernel C's gathers run faster on two 8-byte
@@ -634,6 +678,12 @@ __device__ __forceinline__ void kb_sort_piece(const KbPlan &plan, const KbScratc
     } else {
         for (uint32_t i = threadIdx.x; i < len; i += KB_THREADS) s.ent[dst0 + i] = slo[i];
     }
+#ifdef KB_TIMING
+    KB_T(s.trash, 7);                                                   // write-out issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    KB_T(s.trash, 8);                                                   // ... and drained
+    if (threadIdx.x == 0) atomicAdd((unsigned long long *)&s.trash[8 + 9], 1ull);
+#endif
 }
 
 // first launch: workgroup = pair (g, c), its first piece.  Workgroups are dealt to the 8 XCDs round robin by blockIdx
@@ -648,6 +698,228 @@ __global__ __launch_bounds__(KB_THREADS) void kb_piecesort_kernel(KbPlan plan, K
     if (pair >= n_pairs) return;
     kb_sort_piece<KW>(plan, s, s.pass + pass_idx, smem, pair, 0);
 }
+// first launch, PIPELINED (the default): one persistent workgroup per CU walks its share of the pairs, three pieces in
+// flight at different stages --
+//   piece i + 3: the loads of its slabs' bin offsets and of its place in the ring are issued;
+//   piece i + 2: run table from those offsets (block scan), then all EPT gather loads of every lane are issued into a
+//                SECOND set of registers;
+//   piece i + 1: its entries have arrived and wait in registers;
+//   piece i:     rank by fine bin, scan, scatter into the LDS image, write-out.
+// With one workgroup per CU (the image is 128 KB) kb_piecesort_kernel pays, piece after piece, a global latency for the
+// offsets, another for the gather and the drain of 128 KB of stores, with the vector units idle meanwhile (7.6 us of issue
+// in 24.6 us per piece); here the gather of the next piece is in flight under the LDS phases of this one and the stores
+// drain under the next.  Barriers order LDS traffic only (kb_lds_barrier): a __syncthreads() would wait for the loads in
+// flight.  An XCD still takes a contiguous eighth of the pairs, its workgroups interleaved over them, so a group's offset
+// rows are fetched into one L2 once.
+__device__ __forceinline__ uint32_t kb_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ unsigned long long kb_uni64(unsigned long long v) {
+    return ((unsigned long long)kb_uni((uint32_t)(v >> 32)) << 32) | kb_uni((uint32_t)v);
+}
+__device__ __forceinline__ uint32_t kb_block_exscan_lds(uint32_t v, uint32_t *wsum /* >= 17 words LDS */, uint32_t tid) {
+    const int lane = tid & 63, wave = tid >> 6, nw = KB_THREADS >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[wave] = inc;
+    kb_lds_barrier();
+    if (wave == 0) {
+        uint32_t sv = lane < nw ? wsum[lane] : 0, si = sv;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { uint32_t t = __shfl_up(si, o); if (lane >= o) si += t; }
+        if (lane < nw) wsum[lane] = si - sv;
+    }
+    kb_lds_barrier();
+    const uint32_t r = wsum[wave] + inc - v;
+    kb_lds_barrier();
+    return r;
+}
+
+// One iteration of the pipelined piece sort (see kb_piecesort_pipe_kernel) on ONE of its two register sets: piece `it`,
+// whose entries were requested into (klo, khi) two iterations ago, is sorted and written out, and the entries of piece
+// it + 2 are requested into the same registers.  EVERY global load and store of the body is unconditional -- lanes and
+// whole iterations that have nothing to do read a valid dummy address and re-store a value to where it already is (or
+// to the trash words) -- so that the number of vector-memory instructions between a request and its use is the same on
+// every path: vmcnt retires in issue order, and only then can the compiler wait for "all but the N youngest" instead of
+// for everything (which would include the gather just issued).
+template <int KW>
+struct KbPipe {
+    static constexpr int CHUNK = KbCfg<KW>::CHUNK, EPT = CHUNK / KB_THREADS, SLAB = KbCfg<KW>::SLAB;
+    // LDS
+    uint64_t *slo; KbEnt2 *s2; uint32_t *hist, *offs, *wsum, *rpre; unsigned long long *rsrc;
+    // loop invariants
+    const KbPass *P; uint32_t nb, n_pairs, eighth, xcd, j0, nj; int n_it, nf; unsigned long long row_base, ent_base;
+    // O -> R: what was loaded for the piece whose run table comes next (raw: made scalars where they are used)
+    uint32_t o_pair = 0, o_npair = 0, o_raw = 0, o_rowoff = 0, o_binrow = 0; bool o_ok = false;
+    unsigned long long o_entoff = 0, o_binent = 0;
+
+    __device__ __forceinline__ void iter(const KbPlan &plan, const KbScratch &s, int it, uint64_t (&klo)[EPT], uint64_t (&khi)[KW == 2 ? EPT : 1],
+                                         uint32_t &m_len, unsigned long long &m_row, unsigned long long &m_dst0) {
+        // (the thread index is made opaque once per iteration: the compiler would otherwise keep every per-lane address of
+        // the loop body in a register of its own across the whole loop -- ~50 VGPRs, i.e. spills at the 128 this kernel has)
+        uint32_t tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const uint32_t wbase = (tid >> 6) * (64 * EPT) + (tid & 63);      // this lane's first entry of a piece
+        // ---- (a) LDS phases of piece `it`
+        const uint32_t len = m_len;
+        if (len) {                                                        // (uniform; LDS only)
+            uint32_t rk[EPT / 2];                                         // ranks inside the fine bin, two to a register
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+                uint32_t r = 0;
+                if (wbase + 64 * q < len) r = atomicAdd(&hist[kb_fine(plan, klo[q])], 1u);
+                if (q & 1) rk[q >> 1] |= r << 16; else rk[q >> 1] = r;
+            }
+            kb_lds_barrier();
+            {
+                const uint32_t v = (int)tid < nf ? hist[tid] : 0;
+                const uint32_t ex = kb_block_exscan_lds(v, wsum, tid);
+                if ((int)tid < nf) { offs[tid] = ex; hist[tid] = 0; }    // (hist: for the next piece)
+            }
+            kb_lds_barrier();
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+                if (wbase + 64 * q < len) {
+                    const uint32_t pos = offs[kb_fine(plan, klo[q])] + ((rk[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu);
+                    if constexpr (KW == 2) s2[pos] = KbEnt2{klo[q], khi[q]};
+                    else slo[pos] = klo[q];
+                }
+            }
+            kb_lds_barrier();
+        }
+        const unsigned long long w_row = m_row, w_dst0 = m_dst0;
+        // ---- (b) run table of piece it + 2 (its offsets were requested one iteration ago; LDS only)
+        m_len = 0;
+        uint32_t r_ns = 1, r_npair = 1;
+        {
+            const uint32_t npair = o_ok ? kb_uni(o_npair) : 0u;
+            if (npair) {                                                  // (uniform) an empty pair has no piece
+                const uint32_t g = o_pair / nb;
+                const uint64_t s0 = (uint64_t)g * plan.group;
+                const uint32_t ns = (uint32_t)min((uint64_t)plan.group, (uint64_t)plan.n_slabs - s0);
+                const uint32_t o_o0 = o_raw & 0xFFFFu, o_o1 = o_raw >> 16;
+                const uint32_t rl = tid < ns ? o_o1 - o_o0 : 0u;
+                const uint32_t pre = kb_block_exscan_lds(rl, wsum, tid);
+                if (tid < ns) {
+                    rsrc[tid] = (s0 + tid) * (unsigned long long)SLAB + o_o0 - pre;
+                    rpre[tid] = pre;
+                }
+                if (tid < 4) rpre[ns + tid] = npair;
+                m_row = row_base + kb_uni(o_binrow) + kb_uni(o_rowoff);
+                m_dst0 = ent_base + kb_uni64(o_binent) + kb_uni64(o_entoff);
+                m_len = min((uint32_t)CHUNK, npair);                     // its first piece; the others: kb_piecesort_more_kernel
+                r_ns = ns; r_npair = npair;
+                kb_lds_barrier();
+            }
+        }
+        // ---- (c) write-out of piece `it`: its row of run offsets, its place in the ring, the image
+        {
+            uint32_t *co = len ? s.chunk_off + w_row * plan.off_stride : (uint32_t *)s.trash;
+            const uint32_t ci = len ? min(tid, (uint32_t)nf) : 0u;
+            co[ci] = (int)tid < nf ? offs[ci] : len;                     // (lanes past the row all store its last word)
+            unsigned long long *re = len ? s.row_ent + w_row : (unsigned long long *)s.trash + 1;
+            uint32_t *rl_ = len ? s.row_len + w_row : (uint32_t *)s.trash + 4;
+            *re = w_dst0; *rl_ = len;
+            const uint32_t last = len ? len - 1 : 0u;
+            if constexpr (KW == 2) {
+                uint64_t *d = len ? s.ent + 2 * w_dst0 : s.trash + 4;
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) {
+                    const uint32_t i = min(tid + KB_THREADS * q, last);
+                    const KbEnt2 v = s2[i];
+                    d[i] = v.lo; d[len + i] = v.hi;
+                }
+            } else {
+                uint64_t *d = len ? s.ent + w_dst0 : s.trash + 4;
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) {
+                    const uint32_t i = min(tid + KB_THREADS * q, last);  // (lanes past the piece store its last entry again)
+                    d[i] = slo[i];
+                }
+            }
+        }
+        // ---- (e) offsets of piece it + 3
+        {
+            const int i3 = it + 3;
+            const uint32_t jj = j0 + (uint32_t)i3 * nj;
+            const uint32_t pair = xcd * eighth + jj;
+            o_ok = i3 >= 0 && i3 < n_it && jj < eighth && pair < n_pairs;
+            const uint32_t pc = o_ok ? pair : 0u;                         // (nothing to do: pair 0 is read, and ignored)
+            const uint32_t g = pc / nb, c = pc % nb;
+            const uint64_t s0 = (uint64_t)g * plan.group;
+            const uint32_t ns = (uint32_t)min((uint64_t)plan.group, (uint64_t)plan.n_slabs - s0);
+            o_pair = pc;
+            o_npair = s.gn[pc]; o_rowoff = s.gpre_row[pc]; o_entoff = s.gpre_ent[pc];
+            o_binrow = P->binrow_first[c]; o_binent = P->binent_first[c];
+            const uint32_t tt = tid < ns ? tid : 0u;
+            __builtin_memcpy(&o_raw, s.off + (s0 + tt) * (uint64_t)(nb + 1) + c, 4);    // off[c], off[c + 1]: split where they are used
+        }
+        // ---- (d) gather of piece it + 2 into the registers piece `it` has left: all loads of a lane in flight together
+        {
+            const uint32_t glen = m_len;
+            uint32_t cr = 0, cnx = 0; unsigned long long cs = 0;
+            if (wbase < glen) {
+                const uint32_t e = wbase;
+                uint32_t gu = (uint32_t)(((unsigned long long)e * r_ns) / r_npair);
+                gu = gu < r_ns ? gu : r_ns - 1;
+                while (rpre[gu] > e) --gu;
+                while (rpre[gu + 1] <= e) ++gu;
+                cr = gu; cnx = rpre[cr + 1]; cs = rsrc[cr];
+            }
+            const KbEnt2 *tmp2 = (const KbEnt2 *)s.tmp;
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+                const uint32_t e = wbase + 64 * q;
+                unsigned long long src = 0;                               // (lanes past the piece read entry 0, and ignore it)
+                if (e < glen) {
+                    if (e >= cnx) {
+                        do { ++cr; cnx = rpre[cr + 1]; } while (e >= cnx);
+                        cs = rsrc[cr];
+                    }
+                    src = cs + e;
+                }
+                if constexpr (KW == 2) { const KbEnt2 v = tmp2[src]; klo[q] = v.lo; khi[q] = v.hi; }
+                else klo[q] = s.tmp[src];
+            }
+        }
+        // (the image is read by (c) and written by the next (a) after its two barriers; the run table is read by (d) and
+        // written by the next (b) after the barriers of (a) or of its own scan)
+        kb_lds_barrier();
+    }
+};
+
+template <int KW>
+__global__ __launch_bounds__(KB_THREADS) void kb_piecesort_pipe_kernel(KbPlan plan, KbScratch s, uint32_t pass_idx)
+{
+    constexpr int CHUNK = KbCfg<KW>::CHUNK, EPT = CHUNK / KB_THREADS;
+    static_assert(EPT % 2 == 0 && CHUNK <= 65536, "ranks are kept two to a register");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    KbPipe<KW> p;
+    p.slo = (uint64_t *)smem; p.s2 = (KbEnt2 *)smem;
+    p.hist = (uint32_t *)(smem + (size_t)CHUNK * 8 * KW);               // [KB_F]
+    p.offs = p.hist + KB_F;                                              // [KB_F]
+    p.wsum = p.offs + KB_F;                                              // [32]
+    p.rsrc = (unsigned long long *)(p.wsum + 32);                       // [KB_G_MAX]
+    p.rpre = (uint32_t *)(p.rsrc + KB_G_MAX);                           // [KB_G_MAX + 4]
+    p.P = s.pass + pass_idx;
+    p.nb = 1u << plan.c1; p.n_pairs = plan.n_groups << plan.c1;
+    p.eighth = (p.n_pairs + 7) >> 3;
+    p.xcd = blockIdx.x & 7; p.j0 = blockIdx.x >> 3; p.nj = gridDim.x >> 3;                 // (the grid is a multiple of 8)
+    p.n_it = p.j0 < p.eighth ? (int)((p.eighth - p.j0 + p.nj - 1) / p.nj) : 0;
+    p.nf = 1 << plan.c2;
+    p.row_base = p.P->row_base; p.ent_base = p.P->ent_base;
+    for (int i = threadIdx.x; i < KB_F; i += KB_THREADS) p.hist[i] = 0;
+    kb_lds_barrier();
+    // two register sets: piece k lives in set k & 1 from the iteration that requests it (k - 2) to the one that sorts it (k)
+    uint64_t alo[EPT], ahi[KW == 2 ? EPT : 1], blo[EPT], bhi[KW == 2 ? EPT : 1];
+    uint32_t a_len = 0, b_len = 0; unsigned long long a_row = 0, a_dst0 = 0, b_row = 0, b_dst0 = 0;
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) { alo[q] = 0; blo[q] = 0; if constexpr (KW == 2) { ahi[q] = 0; bhi[q] = 0; } }
+    for (int it = -4; it < p.n_it; it += 2) {
+        p.iter(plan, s, it, alo, ahi, a_len, a_row, a_dst0);
+        p.iter(plan, s, it + 1, blo, bhi, b_len, b_row, b_dst0);
+    }
+}
+
 // second launch: the pieces beyond a pair's first (skewed input only); a few persistent workgroups walk the list
 template <int KW>
 __global__ __launch_bounds__(KB_THREADS) void kb_piecesort_more_kernel(KbPlan plan, KbScratch s, uint32_t pass_idx)
@@ -960,7 +1232,7 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
                         do { ++cr; cpf = cnx; cnx = rpw[cr + 2]; } while (ei >= cnx);
                         cf = run_first[cr];
                     }
-                    bklo[q] = s.ent[cf + (ei - cpf)];
+                    bklo[q] = s.ent[(plan.dbg & 256) ? ((cf + (ei - cpf)) & 0x3FFFFull) : cf + (ei - cpf)];      // (ablation 256: entries from 2 MB -- timing only)
                 }
             }
           } else {
@@ -1189,6 +1461,7 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
     // the value it had in HBM: saturate those (Jellyfish's 4-byte counter).
     // two slots per lane and step: 16-byte LDS reads and HBM stores for the keys, 8-byte ones for the counts
     // (slot0 is a multiple of B, B is even: everything stays aligned)
+    if (plan.dbg & 512) return;                                         // (ablation 512: no write-back -- timing only)
     for (uint32_t i = threadIdx.x; i < B / 2; i += CT) {
         if constexpr (MODE == KB_MODE_INSERT) {
             ((ulonglong2 *)(t.lo + slot0))[i] = ((const ulonglong2 *)tlo)[i];

@@ -769,6 +769,7 @@ static int kb_set_lds_attrs(kdf_engine *h, size_t a, size_t b, size_t c, size_t 
     HIPCHK(h, hipFuncSetAttribute((const void *)(kb_slabsort_kernel<KW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a));
     HIPCHK(h, hipFuncSetAttribute((const void *)kb_piecesort_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b));
     HIPCHK(h, hipFuncSetAttribute((const void *)kb_piecesort_more_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b));
+    HIPCHK(h, hipFuncSetAttribute((const void *)kb_piecesort_pipe_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b));
     const size_t cbig = KB_C_LDS(KW, KB_BB_SMALL(KW) + 1);
 #define KB_SETV(V) \
     HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_INSERT, V, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c)); \
@@ -790,8 +791,8 @@ static int table_rehash(kdf_engine *h, uint32_t new_log2);
 // the small device arrays of the binned path, allocated once per engine; fills the pointers of `s` from the engine's buffers
 static int kb_scratch(kdf_engine *h, KbScratch &s) {
     if (!h->kb_small) {
-        HIPCHK(h, hipMalloc((void **)&h->kb_small, 16 * 8));
-        HIPCHK(h, hipMemsetAsync(h->kb_small, 0, 16 * 8, h->stream));
+        HIPCHK(h, hipMalloc((void **)&h->kb_small, (16 + 32) * 8));
+        HIPCHK(h, hipMemsetAsync(h->kb_small, 0, (16 + 32) * 8, h->stream));
         HIPCHK(h, hipHostMalloc((void **)&h->kb_totals_host, 16 * 8));
         HIPCHK(h, hipMalloc((void **)&h->kb_pass, sizeof(KbPass) * KB_MAX_PASS));
     }
@@ -801,7 +802,7 @@ static int kb_scratch(kdf_engine *h, KbScratch &s) {
         HIPCHK(h, hipMemsetAsync((char *)h->kb_heavy + pairs * 12, 0, (4 + 3 * KB_HV_MAX) * 4, h->stream));
     }
     s = KbScratch{};
-    s.totals = h->kb_small;
+    s.totals = h->kb_small; s.trash = (uint64_t *)(h->kb_small + 16);
     s.pass = h->kb_pass;
     if (h->kw == 1 && h->kb_heavy) {
         const size_t pairs = (size_t)KB_HV_MAX * KB_HV_SLICES << (KB_BB_SMALL(1) + 1);
@@ -923,7 +924,9 @@ static int kb_partition(kdf_engine *h, const uint64_t *d_packed, const uint64_t 
     stamp();                                                   // end of the planning kernels
     // No host round trip: the pass's share of the ring is sized for one entry per position; B's first launch has one
     // workgroup per (group, bin) pair, its second walks the (usually empty) list of further pieces.
-    hipLaunchKernelGGL(kb_piecesort_kernel<KW>, dim3((unsigned)((n_pairs + 7) / 8 * 8)), dim3(KB_THREADS), lds_b, h->stream, plan, s, pass_idx);
+    // (debug flag 64: the one-piece-per-workgroup kernel of round 3's first half, for same-box comparisons)
+    if (plan.dbg & 64) hipLaunchKernelGGL(kb_piecesort_kernel<KW>, dim3((unsigned)((n_pairs + 7) / 8 * 8)), dim3(KB_THREADS), lds_b, h->stream, plan, s, pass_idx);
+    else hipLaunchKernelGGL(kb_piecesort_pipe_kernel<KW>, dim3((unsigned)std::max(8, h->n_cu / 8 * 8)), dim3(KB_THREADS), lds_b, h->stream, plan, s, pass_idx);
     hipLaunchKernelGGL(kb_piecesort_more_kernel<KW>, dim3((unsigned)std::min<uint64_t>(ovf_cap, (uint64_t)h->n_cu)), dim3(KB_THREADS), lds_b, h->stream, plan, s, pass_idx);
     stamp();                                                   // end of B
     HIPCHK(h, hipGetLastError());
@@ -1002,6 +1005,7 @@ static int kb_flush_ring(kdf_engine *h) {
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, h->stream);
         hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, h->stream); sev.push_back(e);
     }
+    if (plan.dbg & 2048) return kb_ring_reset(h);                 // (ablation: the partition passes are timed alone, what they wrote is dropped)
     const bool heavy = skewed && h->kw == 1 && !filtered && s.hv_ctr && plan.sub_bits == 0;
     if (heavy) {
         HIPCHK(h, hipMemsetAsync(s.hv_ctr, 0, (4 + 3 * KB_HV_MAX) * 4, h->stream));
@@ -2152,6 +2156,14 @@ int kdf_get_stat(kdf_engine *h, const char *name, int64_t *value) {
     else if (n == "hash_shift") *value = h->opt_hash_shift;
     else if (n == "log2cap") *value = h->t.log2cap;
     else if (n == "bucket_bits") *value = h->t.bucket_bits;
+    else if (n.rfind("trash", 0) == 0 && n.size() > 5 && h->kb_small) {          // (variant builds with -DKB_TIMING: phase cycle sums)
+        const int i = atoi(n.c_str() + 5);
+        if (i < 0 || i >= 32) return fail(h, KDF_ERR_INVALID, "kdf_get_stat: trash0..trash31");
+        unsigned long long v = 0;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpy(&v, h->kb_small + 16 + i, 8, hipMemcpyDeviceToHost));
+        *value = (int64_t)v;
+    }
     else return fail(h, KDF_ERR_INVALID, "kdf_get_stat: unknown stat %s", name);
     return KDF_OK;
 }

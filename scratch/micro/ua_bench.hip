@@ -69,5 +69,18 @@ int main() {
         printf("mode %d (%s): %.3f ms, %.2f TB/s of entry bytes, %.1f G entries/s\n", mode, mode == 0 ? "8 B aligned" : mode == 1 ? "6 B, one unaligned dwordx2" : "6 B, dword + short",
                best, bytes / best / 1e9, n_ent / best / 1e6);
     }
+    // run length: the same bytes in runs of 16 ... 256 entries (8-byte entries, aligned loads; runs start 8-byte aligned only: + 1 entry of skew per run)
+    for (uint32_t rl = 16; rl <= 256; rl *= 2) {
+        const uint32_t rn = runs * run_len / rl;
+        float best = 1e9;
+        for (int it = 0; it < 3; ++it) {
+            CK(hipEventRecord(a));
+            gather<0><<<nb, CT>>>(ring + 8 * (rl == run_len ? 0 : 1), out, nb, rn, rl - (rl == run_len ? 0 : 1));
+            CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+            float ms; CK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
+        }
+        const double bytes = (double)nb * rn * (rl - (rl == run_len ? 0 : 1)) * 8;
+        printf("runs of %u entries (%u B): %.3f ms, %.2f TB/s\n", rl - (rl == run_len ? 0 : 1), 8 * (rl - (rl == run_len ? 0 : 1)), best, bytes / best / 1e9);
+    }
     return 0;
 }
