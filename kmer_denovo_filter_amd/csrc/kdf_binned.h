@@ -417,6 +417,9 @@ __global__ __launch_bounds__(KB_A_THREADS) void kb_slabsort_kernel(
             for (int i = threadIdx.x; i <= nb; i += NT) { orow[i] = (uint16_t)offs[i]; hist[i] = 0; }
             if (threadIdx.x == 0) hist[DUMMY] = 0;
         }
+        // (Measured and dropped, round 3: the NEXT slab's keys computed here, between scatter and B3, with its words
+        // requested before the write-out -- 3.93 against 3.15 ms at k = 31, 6.95 against 5.61 at k = 63: the key arithmetic at
+        // the top of the loop is what the previous slab's 128 KB of stores drain under.)
         // retire the prefetched words of the next slab BEFORE the write-out is issued:
         // vmcnt retires in order, so a later wait for these loads would also wait
         // for every store issued in between
@@ -829,12 +832,22 @@ struct KbPipe {
                     d[i] = v.lo; d[len + i] = v.hi;
                 }
             } else {
+                // 16 bytes per lane and store (8-byte stores run at 0.54-0.70 of that rate, MI355X_MICROARCH.md; the
+                // write-out ISSUE was 14.7 % of the one-piece-per-workgroup kernel's time): the pairs start at the first
+                // entry whose place in the ring is 16-byte aligned; the piece's first and last entry go out once more by
+                // themselves (one store each, every lane the same word), whichever of them a pair has left out
                 uint64_t *d = len ? s.ent + w_dst0 : s.trash + 4;
+                const uint32_t a = len ? (uint32_t)(w_dst0 & 1) : 0u;
+                const uint32_t npairs = len > a ? (len - a) >> 1 : 0u;
+                ulonglong2 *dp = npairs ? (ulonglong2 *)(d + a) : (ulonglong2 *)(s.trash + 4);
+                const uint64_t *sp = npairs ? slo + a : slo;
+                const uint32_t lastp = npairs ? npairs - 1 : 0u;
 #pragma unroll
-                for (int q = 0; q < EPT; ++q) {
-                    const uint32_t i = min(tid + KB_THREADS * q, last);  // (lanes past the piece store its last entry again)
-                    d[i] = slo[i];
+                for (int q = 0; q < EPT / 2; ++q) {
+                    const uint32_t pi = min(tid + KB_THREADS * q, lastp); // (lanes past the piece store its last pair again)
+                    dp[pi] = ulonglong2{sp[2 * pi], sp[2 * pi + 1]};
                 }
+                d[0] = slo[0]; d[last] = slo[last];
             }
         }
         // ---- (e) offsets of piece it + 3
