@@ -824,13 +824,23 @@ struct KbPipe {
             *re = w_dst0; *rl_ = len;
             const uint32_t last = len ? len - 1 : 0u;
             if constexpr (KW == 2) {
+                // (the piece goes out as len h words, then len hi words -- see kb_sort_piece -- each array in 16-byte
+                // stores of two words; the hi words start on an odd word when len is odd: their pairs start one further,
+                // and the words a pair leaves out -- last h, first and last hi -- go out by themselves, every lane the same)
                 uint64_t *d = len ? s.ent + 2 * w_dst0 : s.trash + 4;
+                const uint64_t *sw = (const uint64_t *)s2;              // word 2 i = h of entry i, word 2 i + 1 = its hi
+                const uint32_t ah = len & 1;
+                const uint32_t npl = len >> 1, nph = len > ah ? (len - ah) >> 1 : 0u;
+                ulonglong2 *dl = npl ? (ulonglong2 *)d : (ulonglong2 *)(s.trash + 4);
+                ulonglong2 *dh = nph ? (ulonglong2 *)(d + len + ah) : (ulonglong2 *)(s.trash + 6);
+                const uint32_t lastl = npl ? npl - 1 : 0u, lasth = nph ? nph - 1 : 0u, ahh = nph ? ah : 0u;
 #pragma unroll
-                for (int q = 0; q < EPT; ++q) {
-                    const uint32_t i = min(tid + KB_THREADS * q, last);
-                    const KbEnt2 v = s2[i];
-                    d[i] = v.lo; d[len + i] = v.hi;
+                for (int q = 0; q < EPT / 2; ++q) {
+                    const uint32_t pl = min(tid + KB_THREADS * q, lastl), ph = min(tid + KB_THREADS * q, lasth);
+                    dl[pl] = ulonglong2{sw[4 * pl], sw[4 * pl + 2]};
+                    dh[ph] = ulonglong2{sw[2 * (ahh + 2 * ph) + 1], sw[2 * (ahh + 2 * ph) + 3]};
                 }
+                d[last] = sw[2 * last]; d[len] = sw[1]; d[len + last] = sw[2 * last + 1];
             } else {
                 // 16 bytes per lane and store (8-byte stores run at 0.54-0.70 of that rate, MI355X_MICROARCH.md; the
                 // write-out ISSUE was 14.7 % of the one-piece-per-workgroup kernel's time): the pairs start at the first

@@ -759,7 +759,10 @@ static KbPlan kb_make_plan(const kdf_engine *h, const KdfTable &t) {
     const uint64_t chunk = h->kw == 1 ? KbCfg<1>::CHUNK : KbCfg<2>::CHUNK, slab = h->kw == 1 ? KbCfg<1>::SLAB : KbCfg<2>::SLAB;
     double dens = 1.0;
     if (h->dens_positions >= (1u << 20)) dens = std::min(1.0, std::max(0.05, 1.03 * (double)h->dens_windows / (double)h->dens_positions));
-    p.group = (uint32_t)std::min<double>(KB_G_MAX, std::max<double>(1.0, 0.93 * (double)chunk * (double)((uint64_t)1 << p.c1) / ((double)slab * dens)));
+    // (0.98 of a piece's capacity, on a density taken 3 % high: pieces come out 95 % full -- 6 sigma below 16 K entries on
+    // uniform input; measured 0.93 / 0.97 / 1.0 / 1.03: pass 12.48 / 12.29 / 12.25 / 13.12 ms, the last with overflow pieces)
+    static const double fill = [] { const char *e = getenv("KDF_PIECE_FILL"); const double v = e ? atof(e) : 0.0; return v > 0.1 && v <= 1.2 ? v : 0.98; }();
+    p.group = (uint32_t)std::min<double>(KB_G_MAX, std::max<double>(1.0, fill * (double)chunk * (double)((uint64_t)1 << p.c1) / ((double)slab * dens)));
     return p;
 }
 
