@@ -77,7 +77,11 @@ static_assert(KB_C_THREADS % 256 == 0 && KB_C_THREADS <= 1024 && KB_C_THREADS_W 
 #define KB_C_CT_BIG 1024
 #define KB_C_CTB(KW, BIG) ((BIG) ? KB_C_CT_BIG : KB_C_CT(KW))
 #define KB_BB_SMALL(KW) ((KW) == 1 ? 12u : 11u)         // bucket bits of tables below the threshold
-#define KB_C_RUNS    256                 // runs (chunks of the coarse bin) staged per round
+#define KB_C_RUNS    256                 // runs (pieces of the coarse bin) staged per round
+#define KB_C_RUNS_BIG 1024               // ... by the big-bucket instantiation: a streamed sample has hundreds of runs per bucket (8 bench
+                                         // batches into 2^32 slots: 736), and every round costs two global latencies that the one
+                                         // workgroup a CU holds there has nothing to hide behind
+#define KB_C_RUNS_T(BIG) ((BIG) ? KB_C_RUNS_BIG : KB_C_RUNS)
 
 // Threads of the slab kernel: 1024 x 16 windows = 16 K-entry slabs (132 KB of LDS, one workgroup per CU).  512 (8 K slabs,
 // two workgroups per CU) measured 4.03 ms against 3.14 for the slab kernel and 6.7 against 5.5 for the piece kernel, whose
@@ -104,7 +108,8 @@ template <> struct KbCfg<2> { static constexpr int WPT = 8,  SLAB = KB_A_THREADS
 // of two 8-byte accesses to two arrays (runs are short).
 struct __attribute__((aligned(16))) KbEnt2 { uint64_t lo, hi; };
 #ifndef KB_G_MAX
-#define KB_G_MAX 1024                    // slabs per group (one thread of the piece kernel per slab)
+#define KB_G_MAX 2048                    // slabs per group: a thread of the piece kernels takes the runs of two consecutive slabs.  (1024,
+                                         // one slab per thread, capped the groups of tables with 1024 coarse bins at 84 % full pieces)
 #endif
 
 struct KbPlan {
@@ -583,19 +588,23 @@ __device__ __forceinline__ void kb_sort_piece(const KbPlan &plan, const KbScratc
     // the run of slab s0 + t in bin c
     const uint64_t s0 = (uint64_t)g * plan.group;
     const uint32_t ns = (uint32_t)min((uint64_t)plan.group, (uint64_t)plan.n_slabs - s0);
-    uint32_t o0 = 0, rl = 0;
-    if (threadIdx.x < ns) {
-        const uint16_t *o = s.off + (s0 + threadIdx.x) * (uint64_t)(nb + 1) + c;
-        o0 = o[0]; rl = (uint32_t)o[1] - o0;
+    static_assert(KB_G_MAX == 2 * KB_THREADS, "a thread takes the runs of two consecutive slabs");
+    uint32_t o0 = 0, rl0 = 0, o1 = 0, rl1 = 0;
+    const uint32_t sa = 2 * threadIdx.x;
+    if (sa < ns) {
+        const uint16_t *o = s.off + (s0 + sa) * (uint64_t)(nb + 1) + c;
+        o0 = o[0]; rl0 = (uint32_t)o[1] - o0;
+        if (sa + 1 < ns) { o1 = o[nb + 1]; rl1 = (uint32_t)o[nb + 2] - o1; }
     }
     KB_T(s.trash, 0);                                                   // offsets loaded (the scan below waits for them)
-    const uint32_t pre = kb_block_exscan(rl, wsum, nullptr);            // (barriers inside: hist is zeroed)
+    const uint32_t pre = kb_block_exscan(rl0 + rl1, wsum, nullptr);     // (barriers inside: hist is zeroed)
     KB_T(s.trash, 1);
-    if (threadIdx.x < ns) {
-        rsrc[threadIdx.x] = (s0 + threadIdx.x) * (unsigned long long)SLAB + o0 - pre;
-        rpre[threadIdx.x] = pre;
+    if (sa < ns) {
+        rsrc[sa] = (s0 + sa) * (unsigned long long)SLAB + o0 - pre;
+        rpre[sa] = pre;
+        if (sa + 1 < ns) { rsrc[sa + 1] = (s0 + sa + 1) * (unsigned long long)SLAB + o1 - (pre + rl0); rpre[sa + 1] = pre + rl0; }
     }
-    if (threadIdx.x < 4) rpre[ns + threadIdx.x] = n_pair;               // padding: the run search below stops there (ns may equal the thread count)
+    if (threadIdx.x < 4) rpre[ns + threadIdx.x] = n_pair;               // padding: the run search below stops there
     if (threadIdx.x == 0) { s.row_ent[row] = dst0; s.row_len[row] = len; }
     __syncthreads();
     KB_T(s.trash, 2);
@@ -752,7 +761,7 @@ struct KbPipe {
     // loop invariants
     const KbPass *P; uint32_t nb, n_pairs, eighth, xcd, j0, nj; int n_it, nf; unsigned long long row_base, ent_base;
     // O -> R: what was loaded for the piece whose run table comes next (raw: made scalars where they are used)
-    uint32_t o_pair = 0, o_npair = 0, o_raw = 0, o_rowoff = 0, o_binrow = 0; bool o_ok = false;
+    uint32_t o_pair = 0, o_npair = 0, o_raw = 0, o_raw2 = 0, o_rowoff = 0, o_binrow = 0; bool o_ok = false;
     unsigned long long o_entoff = 0, o_binent = 0;
 
     __device__ __forceinline__ void iter(const KbPlan &plan, const KbScratch &s, int it, uint64_t (&klo)[EPT], uint64_t (&khi)[KW == 2 ? EPT : 1],
@@ -799,12 +808,17 @@ struct KbPipe {
                 const uint32_t g = o_pair / nb;
                 const uint64_t s0 = (uint64_t)g * plan.group;
                 const uint32_t ns = (uint32_t)min((uint64_t)plan.group, (uint64_t)plan.n_slabs - s0);
-                const uint32_t o_o0 = o_raw & 0xFFFFu, o_o1 = o_raw >> 16;
-                const uint32_t rl = tid < ns ? o_o1 - o_o0 : 0u;
-                const uint32_t pre = kb_block_exscan_lds(rl, wsum, tid);
-                if (tid < ns) {
-                    rsrc[tid] = (s0 + tid) * (unsigned long long)SLAB + o_o0 - pre;
-                    rpre[tid] = pre;
+                const uint32_t sa = 2 * tid;                              // this thread's two consecutive slabs
+                const uint32_t o_a0 = o_raw & 0xFFFFu, o_a1 = o_raw >> 16, o_b0 = o_raw2 & 0xFFFFu, o_b1 = o_raw2 >> 16;
+                const uint32_t rl0 = sa < ns ? o_a1 - o_a0 : 0u, rl1 = sa + 1 < ns ? o_b1 - o_b0 : 0u;
+                const uint32_t pre = kb_block_exscan_lds(rl0 + rl1, wsum, tid);
+                if (sa < ns) {
+                    rsrc[sa] = (s0 + sa) * (unsigned long long)SLAB + o_a0 - pre;
+                    rpre[sa] = pre;
+                }
+                if (sa + 1 < ns) {
+                    rsrc[sa + 1] = (s0 + sa + 1) * (unsigned long long)SLAB + o_b0 - (pre + rl0);
+                    rpre[sa + 1] = pre + rl0;
                 }
                 if (tid < 4) rpre[ns + tid] = npair;
                 m_row = row_base + kb_uni(o_binrow) + kb_uni(o_rowoff);
@@ -873,8 +887,9 @@ struct KbPipe {
             o_pair = pc;
             o_npair = s.gn[pc]; o_rowoff = s.gpre_row[pc]; o_entoff = s.gpre_ent[pc];
             o_binrow = P->binrow_first[c]; o_binent = P->binent_first[c];
-            const uint32_t tt = tid < ns ? tid : 0u;
-            __builtin_memcpy(&o_raw, s.off + (s0 + tt) * (uint64_t)(nb + 1) + c, 4);    // off[c], off[c + 1]: split where they are used
+            const uint32_t ta = 2 * tid < ns ? 2 * tid : 0u, tb = 2 * tid + 1 < ns ? 2 * tid + 1 : 0u;
+            __builtin_memcpy(&o_raw, s.off + (s0 + ta) * (uint64_t)(nb + 1) + c, 4);    // off[c], off[c + 1] of its two slabs: split where they are used
+            __builtin_memcpy(&o_raw2, s.off + (s0 + tb) * (uint64_t)(nb + 1) + c, 4);
         }
         // ---- (d) gather of piece it + 2 into the registers piece `it` has left: all loads of a lane in flight together
         {
@@ -1115,14 +1130,16 @@ __device__ __forceinline__ void kb_probe_wide_wave(uint64_t *tlo, uint64_t *thi,
 #define KB_C_LA    2                   // slots of the probe sequence read up front
 #endif
 #define KB_C_QCAPT(KW, CT_) (((KW) == 2 ? KB_C_WQ_W : 128) * ((CT_) / 64))   // queue entries per workgroup
-#define KB_C_LDS_T(KW, BB, CT_) (((size_t)8 * (KW) + 4) * ((size_t)1 << (BB)) + (2 + 32 + KB_C_RUNS) * 4 + (size_t)KB_C_RUNS * 8 + ((KW) == 2 ? (size_t)KB_C_RUNS * 4 : 0) \
-                          + KB_C_QCAPT(KW, CT_) * ((KW) == 2 ? 18 : 10) + 16 + (KB_C_RUNS + 4) * 4 + KB_RI_LDS_BYTES)
-#define KB_C_LDS(KW, BB) KB_C_LDS_T(KW, BB, KB_C_CTB(KW, (BB) > KB_BB_SMALL(KW)))
+#define KB_C_LDS_T(KW, BB, CT_, RUNS_) (((size_t)8 * (KW) + 4) * ((size_t)1 << (BB)) + (2 + 32 + (RUNS_)) * 4 + (size_t)(RUNS_) * 8 + ((KW) == 2 ? (size_t)(RUNS_) * 4 : 0) \
+                          + KB_C_QCAPT(KW, CT_) * ((KW) == 2 ? 18 : 10) + 16 + ((RUNS_) + 4) * 4 + KB_RI_LDS_BYTES)
+#define KB_C_LDS(KW, BB) KB_C_LDS_T(KW, BB, KB_C_CTB(KW, (BB) > KB_BB_SMALL(KW)), KB_C_RUNS_T((BB) > KB_BB_SMALL(KW)))
 template <int KW, int MODE, int VAR, bool BIG = false>
 __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_eu(BIG ? 4 : KB_C_WPE, BIG ? 4 : KB_C_WPE))) void kb_bucket_kernel(
     KbPlan plan, KbScratch s, KdfTable t, KdfCtl *ctl, int table_nonempty)
 {
     constexpr uint32_t CT = KB_C_CTB(KW, BIG), QCAP = KB_C_QCAPT(KW, CT);      // threads and queue entries per workgroup
+    constexpr uint32_t RUNS = KB_C_RUNS_T(BIG);                                // runs staged per round
+    static_assert(RUNS <= CT, "a thread per run");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t B = 1u << plan.bucket_bits;
     uint64_t *tlo = (uint64_t *)smem;                         // [B]
@@ -1130,13 +1147,13 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
     uint32_t *tcnt = (uint32_t *)(smem + (size_t)B * 8 * KW); // [B]
     uint32_t &sh_failed = tcnt[B], &sh_claimed = tcnt[B + 1];
     uint32_t *wsum = tcnt + B + 2;                            // [32]
-    uint32_t *run_pref = wsum + 32;                           // [KB_C_RUNS] exclusive prefix of run lengths
-    unsigned long long *run_first = (unsigned long long *)(run_pref + KB_C_RUNS);   // [KB_C_RUNS] (B + 34 + KB_C_RUNS is even: 8-aligned)
-    uint32_t *run_hi = (uint32_t *)(run_first + KB_C_RUNS);   // [KB_C_RUNS] wide keys only: distance (words) from a run's h words to its hi words
-    uint64_t *qk = (uint64_t *)(run_hi + (KW == 2 ? KB_C_RUNS : 0));   // [QCAP] keys whose probe goes past the lookahead (per wave: QCAP / waves)
+    uint32_t *run_pref = wsum + 32;                           // [RUNS] exclusive prefix of run lengths
+    unsigned long long *run_first = (unsigned long long *)(run_pref + RUNS);   // [RUNS] (B + 34 + RUNS is even: 8-aligned)
+    uint32_t *run_hi = (uint32_t *)(run_first + RUNS);   // [RUNS] wide keys only: distance (words) from a run's h words to its hi words
+    uint64_t *qk = (uint64_t *)(run_hi + (KW == 2 ? RUNS : 0));   // [QCAP] keys whose probe goes past the lookahead (per wave: QCAP / waves)
     uint16_t *qs = (uint16_t *)(qk + QCAP);              // [QCAP] slot to go on from
-    uint64_t *qk2 = (uint64_t *)((uint32_t *)(qs + QCAP) + 2 + KB_C_RUNS + 4);   // [QCAP] wide keys: hi words of the queued keys
-    uint32_t *rpw = (uint32_t *)(qs + QCAP) + 2;                                  // [KB_C_RUNS + 4] run_pref shifted by one, padded with `total`
+    uint64_t *qk2 = (uint64_t *)((uint32_t *)(qs + QCAP) + 2 + RUNS + 4);   // [QCAP] wide keys: hi words of the queued keys
+    uint32_t *rpw = (uint32_t *)(qs + QCAP) + 2;                                  // [RUNS + 4] run_pref shifted by one, padded with `total`
     KbRunIndex ri;
     ri.bind((char *)(qk2 + (KW == 2 ? QCAP : 0)));
 
@@ -1184,9 +1201,9 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
     // fetched by all threads at once (one global latency, not one per run) and
     // laid out in LDS as a flat work list; threads then take entries round
     // robin, so every lane is busy whatever the run lengths are.
-    for (uint32_t rb = 0; rb < n_runs; rb += KB_C_RUNS) {
+    for (uint32_t rb = 0; rb < n_runs; rb += RUNS) {
         uint32_t len = 0, hioff = 0; unsigned long long first = 0;
-        if (threadIdx.x < KB_C_RUNS && rb + threadIdx.x < n_runs) ri.locate<KW>(plan, s, f, rb + threadIdx.x, first, len, hioff);
+        if (threadIdx.x < RUNS && rb + threadIdx.x < n_runs) ri.locate<KW>(plan, s, f, rb + threadIdx.x, first, len, hioff);
         uint32_t total = 0;
         const uint32_t ex = kb_block_exscan(len, wsum, &total);
         if constexpr (VAR == 2 && KW == 1 && MODE == KB_MODE_INSERT) {
@@ -1210,11 +1227,12 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
                 __syncthreads();
             }
         }
-        if (threadIdx.x < KB_C_RUNS) { run_pref[threadIdx.x] = ex; run_first[threadIdx.x] = first; if constexpr (KW == 2) run_hi[threadIdx.x] = hioff; }
-        if (threadIdx.x < KB_C_RUNS + 3) rpw[threadIdx.x + 1] = ex;     // threads past the last run hold ex == total
+        if (threadIdx.x < RUNS) { run_pref[threadIdx.x] = ex; run_first[threadIdx.x] = first; if constexpr (KW == 2) run_hi[threadIdx.x] = hioff; }
+        if (threadIdx.x < RUNS) rpw[threadIdx.x + 1] = ex;              // (threads past the last run hold ex == total)
+        if (threadIdx.x < 3) rpw[RUNS + 1 + threadIdx.x] = total;
         if (threadIdx.x == 0) rpw[0] = 0;
         __syncthreads();
-        const uint32_t nruns = n_runs - rb < (uint32_t)KB_C_RUNS ? n_runs - rb : (uint32_t)KB_C_RUNS;
+        const uint32_t nruns = n_runs - rb < (uint32_t)RUNS ? n_runs - rb : (uint32_t)RUNS;
         constexpr int EPB = KW == 2 ? KB_C_EPB_W : KB_C_EPB_N;    // entries per thread per batch: EPB (x KW) loads in flight per lane
         // (ei * inv_total) >> 32 ~= ei * nruns / total
         const unsigned long long inv_total = total ? (((unsigned long long)nruns << 32) / total) : 0;
