@@ -81,7 +81,10 @@ static_assert(KB_C_THREADS % 256 == 0 && KB_C_THREADS <= 1024 && KB_C_THREADS_W 
 #define KB_C_RUNS_BIG 1024               // ... by the big-bucket instantiation: a streamed sample has hundreds of runs per bucket (8 bench
                                          // batches into 2^32 slots: 736), and every round costs two global latencies that the one
                                          // workgroup a CU holds there has nothing to hide behind
-#define KB_C_RUNS_T(BIG) ((BIG) ? KB_C_RUNS_BIG : KB_C_RUNS)
+#ifndef KB_C_RUNS_N
+#define KB_C_RUNS_N  512                 // narrow keys, ordinary buckets: 73.6 KB of LDS, still two workgroups per CU (wide keys have no room: three per CU)
+#endif
+#define KB_C_RUNS_T(KW, BIG) ((BIG) ? KB_C_RUNS_BIG : (KW) == 1 ? KB_C_RUNS_N : KB_C_RUNS)
 
 // Threads of the slab kernel: 1024 x 16 windows = 16 K-entry slabs (132 KB of LDS, one workgroup per CU).  512 (8 K slabs,
 // two workgroups per CU) measured 4.03 ms against 3.14 for the slab kernel and 6.7 against 5.5 for the piece kernel, whose
@@ -1132,13 +1135,13 @@ __device__ __forceinline__ void kb_probe_wide_wave(uint64_t *tlo, uint64_t *thi,
 #define KB_C_QCAPT(KW, CT_) (((KW) == 2 ? KB_C_WQ_W : 128) * ((CT_) / 64))   // queue entries per workgroup
 #define KB_C_LDS_T(KW, BB, CT_, RUNS_) (((size_t)8 * (KW) + 4) * ((size_t)1 << (BB)) + (2 + 32 + (RUNS_)) * 4 + (size_t)(RUNS_) * 8 + ((KW) == 2 ? (size_t)(RUNS_) * 4 : 0) \
                           + KB_C_QCAPT(KW, CT_) * ((KW) == 2 ? 18 : 10) + 16 + ((RUNS_) + 4) * 4 + KB_RI_LDS_BYTES)
-#define KB_C_LDS(KW, BB) KB_C_LDS_T(KW, BB, KB_C_CTB(KW, (BB) > KB_BB_SMALL(KW)), KB_C_RUNS_T((BB) > KB_BB_SMALL(KW)))
+#define KB_C_LDS(KW, BB) KB_C_LDS_T(KW, BB, KB_C_CTB(KW, (BB) > KB_BB_SMALL(KW)), KB_C_RUNS_T(KW, (BB) > KB_BB_SMALL(KW)))
 template <int KW, int MODE, int VAR, bool BIG = false>
 __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_eu(BIG ? 4 : KB_C_WPE, BIG ? 4 : KB_C_WPE))) void kb_bucket_kernel(
     KbPlan plan, KbScratch s, KdfTable t, KdfCtl *ctl, int table_nonempty)
 {
     constexpr uint32_t CT = KB_C_CTB(KW, BIG), QCAP = KB_C_QCAPT(KW, CT);      // threads and queue entries per workgroup
-    constexpr uint32_t RUNS = KB_C_RUNS_T(BIG);                                // runs staged per round
+    constexpr uint32_t RUNS = KB_C_RUNS_T(KW, BIG);                                // runs staged per round
     static_assert(RUNS <= CT, "a thread per run");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t B = 1u << plan.bucket_bits;
