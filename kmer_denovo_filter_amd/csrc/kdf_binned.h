@@ -161,7 +161,8 @@ struct KbScratch {
     // heavy buckets of a skewed flush (kb_heavy_slice_kernel): [0] how many, their ids, staged (key, count) pairs
     uint32_t *hv_ctr;               // [4]
     uint32_t *hv_bucket, *hv_n, *hv_failed;   // [KB_HV_MAX]
-    uint64_t *hv_key;               // [KB_HV_MAX][KB_HV_SLICES << 12]
+    uint64_t *hv_key;               // [KB_HV_MAX][KB_HV_SLICES << bucket bits] stored forms (wide: + hv_khi, the keys' high words)
+    uint64_t *hv_khi;
     uint32_t *hv_cnt;
     uint64_t *trash;                // [32] words nobody reads: where the pipelined piece sort stores when it has nothing to store
 };
@@ -1089,7 +1090,7 @@ __device__ __forceinline__ void kb_probe_narrow(uint64_t *tlo, uint32_t *tcnt, u
 // One ATTEMPT from slot `sl`: 0 done, 1 bucket full, 2 blocked.
 template <int MODE>
 __device__ __forceinline__ int kb_probe_wide_once(uint64_t *tlo, uint64_t *thi, uint32_t *tcnt, uint32_t bmask,
-                                                  uint64_t klo, uint64_t khi, uint32_t sl, uint32_t &claimed) {
+                                                  uint64_t klo, uint64_t khi, uint32_t sl, uint32_t &claimed, uint32_t add = 1u) {
     for (uint32_t n = 0; n <= bmask; ++n) {
         uint64_t c = __hip_atomic_load(&tlo[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (c == KDF_EMPTY) {
@@ -1098,13 +1099,13 @@ __device__ __forceinline__ int kb_probe_wide_once(uint64_t *tlo, uint64_t *thi, 
             if (c == KDF_EMPTY) {
                 __hip_atomic_store(&thi[sl], khi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 claimed++;
-                atomicAdd(&tcnt[sl], 1u);
+                if (add == 1u) atomicAdd(&tcnt[sl], 1u); else kb_lds_sat_add(&tcnt[sl], add);
                 return 0;
             }
         }
         if (c == klo) {
             const uint64_t h2 = __hip_atomic_load(&thi[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (h2 == khi) { atomicAdd(&tcnt[sl], 1u); return 0; }
+            if (h2 == khi) { if (add == 1u) atomicAdd(&tcnt[sl], 1u); else kb_lds_sat_add(&tcnt[sl], add); return 0; }
             if (h2 == KDF_EMPTY) return 2;                        // claimed, not yet published
         }
         sl = (sl + 1) & bmask;
@@ -1114,10 +1115,10 @@ __device__ __forceinline__ int kb_probe_wide_once(uint64_t *tlo, uint64_t *thi, 
 // all lanes of the wave call this together (`todo`: this lane has a key); returns when every key is placed
 template <int MODE>
 __device__ __forceinline__ void kb_probe_wide_wave(uint64_t *tlo, uint64_t *thi, uint32_t *tcnt, uint32_t bmask, bool todo,
-                                                   uint64_t klo, uint64_t khi, uint32_t sl, uint32_t &claimed, bool &failed) {
+                                                   uint64_t klo, uint64_t khi, uint32_t sl, uint32_t &claimed, bool &failed, uint32_t add = 1u) {
     while (__any(todo)) {
         if (todo) {
-            const int res = kb_probe_wide_once<MODE>(tlo, thi, tcnt, bmask, klo, khi, sl, claimed);
+            const int res = kb_probe_wide_once<MODE>(tlo, thi, tcnt, bmask, klo, khi, sl, claimed, add);
             if (res != 2) { todo = false; if (res == 1) failed = true; }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1209,7 +1210,7 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
         if (threadIdx.x < RUNS && rb + threadIdx.x < n_runs) ri.locate<KW>(plan, s, f, rb + threadIdx.x, first, len, hioff);
         uint32_t total = 0;
         const uint32_t ex = kb_block_exscan(len, wsum, &total);
-        if constexpr (VAR == 2 && KW == 1 && MODE == KB_MODE_INSERT) {
+        if constexpr (VAR == 2 && MODE == KB_MODE_INSERT) {
             // A heavy bucket (a few keys of enormous multiplicity) is not for ONE workgroup: it is left untouched here, as
             // a failed bucket would be, and KB_HV_SLICES workgroups share its runs afterwards (kb_heavy_slice_kernel).
             if (rb == 0 && total > KB_C_HEAVY && s.hv_ctr && plan.sub_bits == 0) {   // (the host launches the heavy kernels under the same conditions)
@@ -1224,7 +1225,10 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
                 if (threadIdx.x == 0) sh_failed = 0;
                 if (taken) {
                     if (!table_nonempty)
-                        for (uint32_t i = threadIdx.x; i < B; i += CT) { t.lo[slot0 + i] = KDF_EMPTY; t.cnt[slot0 + i] = 0; }
+                        for (uint32_t i = threadIdx.x; i < B; i += CT) {
+                            t.lo[slot0 + i] = KDF_EMPTY; t.cnt[slot0 + i] = 0;
+                            if constexpr (KW == 2) t.hi[slot0 + i] = KDF_EMPTY;
+                        }
                     return;
                 }
                 __syncthreads();
@@ -1566,6 +1570,7 @@ __global__ __launch_bounds__(256) void kb_replay_kernel(KbPlan plan, KbScratch s
 // kernel C would have: slice in LDS, transactional (no room: the bucket is flagged for the replay pass and stays as it was).
 // Measured on the repeat-rich 100 Mbp genome (38 heavy buckets, the heaviest 15.9 M entries): kernel C 10.0 -> 6.2 ms, the
 // pass 20.1 -> 16.0 ms.
+template <int KW>
 __global__ __launch_bounds__(256) void kb_heavy_slice_kernel(KbPlan plan, KbScratch s) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (!s.hv_ctr) return;
@@ -1573,11 +1578,12 @@ __global__ __launch_bounds__(256) void kb_heavy_slice_kernel(KbPlan plan, KbScra
     if (h >= nh) return;
     const uint32_t B = 1u << plan.bucket_bits, bmask = B - 1;
     uint64_t *tlo = (uint64_t *)smem;
-    uint32_t *tcnt = (uint32_t *)(smem + (size_t)B * 8);
-    KbRunIndex ri; ri.bind(smem + (size_t)B * 12);
+    uint64_t *thi = KW == 2 ? tlo + B : nullptr;
+    uint32_t *tcnt = (uint32_t *)(smem + (size_t)B * 8 * KW);
+    KbRunIndex ri; ri.bind(smem + (size_t)B * (8 * KW + 4));
     __shared__ uint32_t sh_fail, sh_n, sh_base;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    for (uint32_t i = tid; i < B; i += 256) { tlo[i] = KDF_EMPTY; tcnt[i] = 0; }
+    for (uint32_t i = tid; i < B; i += 256) { tlo[i] = KDF_EMPTY; if constexpr (KW == 2) thi[i] = KDF_EMPTY; tcnt[i] = 0; }
     if (tid == 0) { sh_fail = 0; sh_n = 0; }
     const uint64_t bucket = s.hv_bucket[h];
     const uint32_t c = (uint32_t)(bucket >> plan.c2), f = (uint32_t)(bucket & ((1u << plan.c2) - 1));
@@ -1586,34 +1592,48 @@ __global__ __launch_bounds__(256) void kb_heavy_slice_kernel(KbPlan plan, KbScra
     uint32_t claimed = 0; bool failed = false;
     for (uint32_t r = slice; r < n_runs; r += KB_HV_SLICES) {
         unsigned long long first; uint32_t n, hioff;
-        ri.locate<1>(plan, s, f, r, first, n, hioff);
+        ri.locate<KW>(plan, s, f, r, first, n, hioff);
         const uint64_t *ent = s.ent + first;
-        constexpr int U = 8;                                       // entries per thread in flight: one workgroup has to cover the HBM latency alone
+        constexpr int U = KW == 2 ? 4 : 8;                         // entries per thread in flight: one workgroup has to cover the HBM latency alone
         for (uint32_t i0 = 0; i0 < n; i0 += 256 * U) {             // whole waves: the hit counting is a wave operation
-            uint64_t keys[U];
+            uint64_t keys[U], his[KW == 2 ? U : 1];
 #pragma unroll
-            for (int u = 0; u < U; ++u) { const uint32_t i = i0 + u * 256 + tid; keys[u] = i < n ? ent[i] : 0; }
+            for (int u = 0; u < U; ++u) {
+                const uint32_t i = i0 + u * 256 + tid;
+                keys[u] = i < n ? ent[i] : 0;
+                if constexpr (KW == 2) his[u] = i < n ? ent[i + hioff] : 0;
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (i0 + u * 256 >= n) break;                      // (uniform)
-                const bool todo = i0 + u * 256 + tid < n;
+                bool todo = i0 + u * 256 + tid < n;
                 const uint64_t key = keys[u];
                 const uint32_t sl = (uint32_t)(key >> hsh_r) & bmask;
-                const bool hit = todo && tlo[sl] == key;           // the heavy key sits in its home slot after its first insertion
-                kb_count_hits<true>(tcnt, sl, hit);
-                if (todo && !hit) {
-                    // (one slot per step is enough here: almost every entry took the branch above)
-                    uint32_t at = sl; bool done = false;
-                    for (uint32_t p_ = 0; p_ <= bmask && !done; ++p_) {
-                        uint64_t cur = tlo[at];
-                        if (cur == KDF_EMPTY) {
-                            cur = atomicCAS((unsigned long long *)&tlo[at], KDF_EMPTY, key);
-                            if (cur == KDF_EMPTY) { ++claimed; cur = key; }
+                if constexpr (KW == 2) {
+                    const uint64_t khi = his[u];
+                    if (todo && key == KDF_EMPTY) { failed = true; todo = false; }       // (2^-64: the replay path stores it)
+                    // the heavy key sits in its home slot after its first insertion (published: its hi word is there)
+                    const bool hit = todo && __hip_atomic_load(&tlo[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == key
+                                          && __hip_atomic_load(&thi[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == khi;
+                    kb_count_hits<true>(tcnt, sl, hit);
+                    kb_probe_wide_wave<KB_MODE_INSERT>(tlo, thi, tcnt, bmask, todo && !hit, key, khi, sl, claimed, failed);
+                } else {
+                    const bool hit = todo && tlo[sl] == key;       // the heavy key sits in its home slot after its first insertion
+                    kb_count_hits<true>(tcnt, sl, hit);
+                    if (todo && !hit) {
+                        // (one slot per step is enough here: almost every entry took the branch above)
+                        uint32_t at = sl; bool done = false;
+                        for (uint32_t p_ = 0; p_ <= bmask && !done; ++p_) {
+                            uint64_t cur = tlo[at];
+                            if (cur == KDF_EMPTY) {
+                                cur = atomicCAS((unsigned long long *)&tlo[at], KDF_EMPTY, key);
+                                if (cur == KDF_EMPTY) { ++claimed; cur = key; }
+                            }
+                            if (cur == key) { atomicAdd(&tcnt[at], 1u); done = true; }
+                            at = (at + 1) & bmask;
                         }
-                        if (cur == key) { atomicAdd(&tcnt[at], 1u); done = true; }
-                        at = (at + 1) & bmask;
+                        if (!done) failed = true;
                     }
-                    if (!done) failed = true;
                 }
             }
         }
@@ -1636,10 +1656,12 @@ __global__ __launch_bounds__(256) void kb_heavy_slice_kernel(KbPlan plan, KbScra
     uint32_t pos = sh_base + wbase + inc - mine;
     const size_t room = (size_t)KB_HV_SLICES << plan.bucket_bits;
     uint64_t *ok_ = s.hv_key + (size_t)h * room; uint32_t *oc_ = s.hv_cnt + (size_t)h * room;
+    uint64_t *oh_ = KW == 2 ? s.hv_khi + (size_t)h * room : nullptr;
     for (uint32_t i = tid; i < B; i += 256)
-        if (tlo[i] != KDF_EMPTY) { ok_[pos] = tlo[i]; oc_[pos] = tcnt[i]; ++pos; }
+        if (tlo[i] != KDF_EMPTY) { ok_[pos] = tlo[i]; if constexpr (KW == 2) oh_[pos] = thi[i]; oc_[pos] = tcnt[i]; ++pos; }
 }
 
+template <int KW>
 __global__ __launch_bounds__(256) void kb_heavy_combine_kernel(KbPlan plan, KbScratch s, KdfTable t, KdfCtl *ctl, int table_nonempty) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (!s.hv_ctr) return;
@@ -1648,37 +1670,54 @@ __global__ __launch_bounds__(256) void kb_heavy_combine_kernel(KbPlan plan, KbSc
     if (h == 0 && threadIdx.x == 0) s.totals[4] = s.hv_ctr[0];     // (statistics: heavy buckets of this flush; the first KB_HV_MAX were split)
     const uint32_t B = 1u << plan.bucket_bits, bmask = B - 1;
     uint64_t *tlo = (uint64_t *)smem;
-    uint32_t *tcnt = (uint32_t *)(smem + (size_t)B * 8);
+    uint64_t *thi = KW == 2 ? tlo + B : nullptr;
+    uint32_t *tcnt = (uint32_t *)(smem + (size_t)B * 8 * KW);
     __shared__ uint32_t sh_fail, sh_claimed;
     const uint32_t tid = threadIdx.x;
     const uint64_t bucket = s.hv_bucket[h];
     const uint64_t slot0 = bucket << plan.bucket_bits;
+    bool failed = false;
     for (uint32_t i = tid; i < B; i += 256) {
         tlo[i] = table_nonempty ? t.lo[slot0 + i] : KDF_EMPTY;
+        if constexpr (KW == 2) {
+            thi[i] = table_nonempty ? t.hi[slot0 + i] : KDF_EMPTY;
+            if ((tlo[i] == KDF_EMPTY) != (thi[i] == KDF_EMPTY)) failed = true;      // (as kernel C: a stored hash word equal to the empty marker)
+        }
         tcnt[i] = table_nonempty ? t.cnt[slot0 + i] : 0u;
     }
     if (tid == 0) { sh_fail = s.hv_failed[h]; sh_claimed = 0; }
     __syncthreads();
     const size_t room = (size_t)KB_HV_SLICES << plan.bucket_bits;
     const uint64_t *ik = s.hv_key + (size_t)h * room; const uint32_t *ic = s.hv_cnt + (size_t)h * room;
+    const uint64_t *ih = KW == 2 ? s.hv_khi + (size_t)h * room : nullptr;
     const uint32_t n = s.hv_n[h];
     const uint32_t hsh_r = 64 - plan.log2cap;
-    uint32_t claimed = 0; bool failed = false;
-    if (!sh_fail)
-        for (uint32_t i = tid; i < n; i += 256) {
-            const uint64_t key = ik[i]; const uint32_t add = ic[i];
-            uint32_t at = (uint32_t)(key >> hsh_r) & bmask; bool done = false;
-            for (uint32_t p_ = 0; p_ <= bmask && !done; ++p_) {
-                uint64_t cur = tlo[at];
-                if (cur == KDF_EMPTY) {
-                    cur = atomicCAS((unsigned long long *)&tlo[at], KDF_EMPTY, key);
-                    if (cur == KDF_EMPTY) { ++claimed; cur = key; }
-                }
-                if (cur == key) { kb_lds_sat_add(&tcnt[at], add); done = true; }
-                at = (at + 1) & bmask;
+    uint32_t claimed = 0;
+    if (!sh_fail) {
+        if constexpr (KW == 2) {
+            for (uint32_t i0 = 0; i0 < n; i0 += 256) {          // whole waves: the wide claim protocol retries under a wave-uniform loop
+                const uint32_t i = i0 + tid;
+                const bool todo = i < n;
+                const uint64_t key = todo ? ik[i] : 0, khi = todo ? ih[i] : 0; const uint32_t add = todo ? ic[i] : 0;
+                kb_probe_wide_wave<KB_MODE_INSERT>(tlo, thi, tcnt, bmask, todo, key, khi, (uint32_t)(key >> hsh_r) & bmask, claimed, failed, add);
             }
-            if (!done) failed = true;
+        } else {
+            for (uint32_t i = tid; i < n; i += 256) {
+                const uint64_t key = ik[i]; const uint32_t add = ic[i];
+                uint32_t at = (uint32_t)(key >> hsh_r) & bmask; bool done = false;
+                for (uint32_t p_ = 0; p_ <= bmask && !done; ++p_) {
+                    uint64_t cur = tlo[at];
+                    if (cur == KDF_EMPTY) {
+                        cur = atomicCAS((unsigned long long *)&tlo[at], KDF_EMPTY, key);
+                        if (cur == KDF_EMPTY) { ++claimed; cur = key; }
+                    }
+                    if (cur == key) { kb_lds_sat_add(&tcnt[at], add); done = true; }
+                    at = (at + 1) & bmask;
+                }
+                if (!done) failed = true;
+            }
         }
+    }
     if (failed) sh_fail = 1;
     if (claimed) atomicAdd(&sh_claimed, claimed);
     __syncthreads();
@@ -1686,7 +1725,10 @@ __global__ __launch_bounds__(256) void kb_heavy_combine_kernel(KbPlan plan, KbSc
         if (tid == 0) { atomicOr(&s.failed[bucket >> 5], 1u << (bucket & 31)); atomicAdd(&s.totals[2], 1ull); }
         return;                                                    // (kernel C already wrote an empty slice into a lazily cleared table)
     }
-    for (uint32_t i = tid; i < B; i += 256) { t.lo[slot0 + i] = tlo[i]; t.cnt[slot0 + i] = tcnt[i]; }
+    for (uint32_t i = tid; i < B; i += 256) {
+        t.lo[slot0 + i] = tlo[i]; t.cnt[slot0 + i] = tcnt[i];
+        if constexpr (KW == 2) t.hi[slot0 + i] = thi[i];
+    }
     if (tid == 0 && sh_claimed) atomicAdd(&ctl->distinct[(bucket % KDF_SHARDS) * 16], (unsigned long long)sh_claimed);
 }
 

@@ -782,10 +782,8 @@ static int kb_set_lds_attrs(kdf_engine *h, size_t a, size_t b, size_t c, size_t 
     KB_SETV(1)
     KB_SETV(2)
 #undef KB_SETV
-    if (KW == 1) {
-        HIPCHK(h, hipFuncSetAttribute((const void *)kb_heavy_slice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hv));
-        HIPCHK(h, hipFuncSetAttribute((const void *)kb_heavy_combine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hv));
-    }
+    HIPCHK(h, hipFuncSetAttribute((const void *)kb_heavy_slice_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hv));
+    HIPCHK(h, hipFuncSetAttribute((const void *)kb_heavy_combine_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hv));
     return KDF_OK;
 }
 
@@ -799,18 +797,20 @@ static int kb_scratch(kdf_engine *h, KbScratch &s) {
         HIPCHK(h, hipHostMalloc((void **)&h->kb_totals_host, 16 * 8));
         HIPCHK(h, hipMalloc((void **)&h->kb_pass, sizeof(KbPass) * KB_MAX_PASS));
     }
-    if (h->kw == 1 && !h->kb_heavy) {                             // heavy buckets of skewed flushes (kb_heavy_slice_kernel): ~100 MB, once
-        const size_t pairs = (size_t)KB_HV_MAX * KB_HV_SLICES << (KB_BB_SMALL(1) + 1);       // (room for the buckets of big tables)
-        HIPCHK(h, hipMalloc((void **)&h->kb_heavy, pairs * 12 + (4 + 3 * KB_HV_MAX) * 4));
-        HIPCHK(h, hipMemsetAsync((char *)h->kb_heavy + pairs * 12, 0, (4 + 3 * KB_HV_MAX) * 4, h->stream));
+    const size_t hv_pairs = (size_t)KB_HV_MAX * KB_HV_SLICES << (KB_BB_SMALL(h->kw) + 1);   // (room for the buckets of big tables)
+    const size_t hv_pair_bytes = 8 * (size_t)h->kw + 4;
+    if (!h->kb_heavy) {                                           // heavy buckets of skewed flushes (kb_heavy_slice_kernel): ~200 MB, once
+        HIPCHK(h, hipMalloc((void **)&h->kb_heavy, hv_pairs * hv_pair_bytes + (4 + 3 * KB_HV_MAX) * 4));
+        HIPCHK(h, hipMemsetAsync((char *)h->kb_heavy + hv_pairs * hv_pair_bytes, 0, (4 + 3 * KB_HV_MAX) * 4, h->stream));
     }
     s = KbScratch{};
     s.totals = h->kb_small; s.trash = (uint64_t *)(h->kb_small + 16);
     s.pass = h->kb_pass;
-    if (h->kw == 1 && h->kb_heavy) {
-        const size_t pairs = (size_t)KB_HV_MAX * KB_HV_SLICES << (KB_BB_SMALL(1) + 1);
-        s.hv_key = (uint64_t *)h->kb_heavy; s.hv_cnt = (uint32_t *)(s.hv_key + pairs);
-        s.hv_ctr = s.hv_cnt + pairs; s.hv_bucket = s.hv_ctr + 4; s.hv_n = s.hv_bucket + KB_HV_MAX; s.hv_failed = s.hv_n + KB_HV_MAX;
+    if (h->kb_heavy) {
+        s.hv_key = (uint64_t *)h->kb_heavy;
+        s.hv_khi = h->kw == 2 ? s.hv_key + hv_pairs : nullptr;
+        s.hv_cnt = (uint32_t *)(s.hv_key + hv_pairs * h->kw);
+        s.hv_ctr = s.hv_cnt + hv_pairs; s.hv_bucket = s.hv_ctr + 4; s.hv_n = s.hv_bucket + KB_HV_MAX; s.hv_failed = s.hv_n + KB_HV_MAX;
     }
     s.ent = (uint64_t *)h->kb_buf[0]; s.tmp = (uint64_t *)h->kb_buf[1];
     s.chunk_off = (uint32_t *)h->kb_buf[2]; s.failed = (uint32_t *)h->kb_buf[3];
@@ -889,7 +889,7 @@ static int kb_partition(kdf_engine *h, const uint64_t *d_packed, const uint64_t 
     const size_t lds_b = (size_t)CHUNK * 8 * KW + (size_t)(2 * KB_F + 32) * 4 + (size_t)KB_G_MAX * 12 + 32;
     if (!h->attrs_set[KW]) {                                   // once per engine
         const size_t lds_c = KB_C_LDS(KW, KB_BB_SMALL(KW));
-        if ((rc = kb_set_lds_attrs<KW>(h, lds_a, lds_b, lds_c, ((size_t)12 << (KB_BB_SMALL(1) + 1)) + KB_RI_LDS_BYTES))) return rc;
+        if ((rc = kb_set_lds_attrs<KW>(h, lds_a, lds_b, lds_c, ((size_t)(8 * KW + 4) << (KB_BB_SMALL(KW) + 1)) + KB_RI_LDS_BYTES))) return rc;
         h->attrs_set[KW] = true;
     }
     // the pass's own buffers: slab-sorted entries, offset rows, planning arrays (reused by the next pass: stream order)
@@ -1009,7 +1009,7 @@ static int kb_flush_ring(kdf_engine *h) {
         hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, h->stream); sev.push_back(e);
     }
     if (plan.dbg & 2048) return kb_ring_reset(h);                 // (ablation: the partition passes are timed alone, what they wrote is dropped)
-    const bool heavy = skewed && h->kw == 1 && !filtered && s.hv_ctr && plan.sub_bits == 0;
+    const bool heavy = skewed && !filtered && s.hv_ctr && plan.sub_bits == 0;
     if (heavy) {
         HIPCHK(h, hipMemsetAsync(s.hv_ctr, 0, (4 + 3 * KB_HV_MAX) * 4, h->stream));
     }
@@ -1026,9 +1026,14 @@ static int kb_flush_ring(kdf_engine *h) {
     });
     if (heavy) {
         // the buckets the skewed instantiation left aside
-        const size_t lds_h = ((size_t)12 << plan.bucket_bits) + KB_RI_LDS_BYTES;
-        hipLaunchKernelGGL(kb_heavy_slice_kernel, dim3(KB_HV_SLICES, KB_HV_MAX), dim3(256), lds_h, h->stream, plan, s);
-        hipLaunchKernelGGL(kb_heavy_combine_kernel, dim3(KB_HV_MAX), dim3(256), lds_h, h->stream, plan, s, h->t, h->ctl, nonempty);
+        const size_t lds_h = ((size_t)(8 * h->kw + 4) << plan.bucket_bits) + KB_RI_LDS_BYTES;
+        if (h->kw == 1) {
+            hipLaunchKernelGGL(kb_heavy_slice_kernel<1>, dim3(KB_HV_SLICES, KB_HV_MAX), dim3(256), lds_h, h->stream, plan, s);
+            hipLaunchKernelGGL(kb_heavy_combine_kernel<1>, dim3(KB_HV_MAX), dim3(256), lds_h, h->stream, plan, s, h->t, h->ctl, nonempty);
+        } else {
+            hipLaunchKernelGGL(kb_heavy_slice_kernel<2>, dim3(KB_HV_SLICES, KB_HV_MAX), dim3(256), lds_h, h->stream, plan, s);
+            hipLaunchKernelGGL(kb_heavy_combine_kernel<2>, dim3(KB_HV_MAX), dim3(256), lds_h, h->stream, plan, s, h->t, h->ctl, nonempty);
+        }
     }
     HIPCHK(h, hipGetLastError());
     if (h->prof) {

@@ -27,7 +27,7 @@ for gname, g in genomes.items():
     ds = synth_stream(reads, 150, seed=20260417, device="cuda", genome=g)
     torch.cuda.synchronize()
     for pname, path in (("binned", 2),):
-        e = KmerEngine(31, capacity_hint=1 << 28)
+        e = KmerEngine(int(os.environ.get("K", "31")), capacity_hint=1 << 28)
         e.set_option("force_path", path)
         best = first = None
         for it in range(4):
