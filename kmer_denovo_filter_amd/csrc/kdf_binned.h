@@ -164,7 +164,7 @@ struct KbScratch {
     uint64_t *hv_key;               // [KB_HV_MAX][KB_HV_SLICES << bucket bits] stored forms (wide: + hv_khi, the keys' high words)
     uint64_t *hv_khi;
     uint32_t *hv_cnt;
-    uint64_t *trash;                // [32] words nobody reads: where the pipelined piece sort stores when it has nothing to store
+    uint64_t *trash;                // [64] words nobody reads: where the pipelined piece sort stores when it has nothing to store
 };
 #ifndef KB_HV_MAX
 #define KB_HV_MAX    64u                             // heavy buckets split per flush (further ones are processed the ordinary way)
@@ -180,6 +180,15 @@ __device__ __forceinline__ uint32_t kb_coarse(const KbPlan &p, uint64_t h) {
 __device__ __forceinline__ uint32_t kb_fine(const KbPlan &p, uint64_t h) {
     return p.c2 ? (uint32_t)((h >> (64 - p.c1 - p.c2)) & ((1u << p.c2) - 1)) : 0u;
 }
+
+// Ablation flags (debug_flags 256 / 512 / 1024: a kernel without its write-out / with its gather served from L2 / without rank
+// return values -- WRONG results, timing only; scratch/ablate2.py) exist in variant builds only (-DKB_ABLATE): in the product
+// kernels the tests on the flags cost 1-3 % of the instructions.
+#ifdef KB_ABLATE
+#define KB_ABL(plan, bit) (((plan).dbg & (bit)) != 0)
+#else
+#define KB_ABL(plan, bit) (false)
+#endif
 
 // Phase timing of a kernel, for variant builds only (-DKB_TIMING; scratch/build_variant.sh): thread 0 of every workgroup
 // adds the cycles since its last stamp to trash[8 + n] (read back through kdf_get_stat "trashN").
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(KB_A_THREADS) void kb_slabsort_kernel(
             const uint32_t bin = ok ? kb_coarse(plan, hsh) : (uint32_t)DUMMY;
             br[u] = bin << 16;
         }
-        if (plan.dbg & 1024) {                                          // (ablation: counts without ranks -- WRONG results, timing only)
+        if (KB_ABL(plan, 1024)) {                                          // (ablation: counts without ranks -- WRONG results, timing only)
 #pragma unroll
             for (int u = 0; u < WPT; ++u) atomicAdd(&hist[br[u] >> 16], 1u);
         } else {
@@ -440,7 +449,7 @@ __global__ __launch_bounds__(KB_A_THREADS) void kb_slabsort_kernel(
         KB_T(s.trash, 16);
         {
             // ONE contiguous block per slab: 16 bytes per lane and step
-            const uint32_t nv = (plan.dbg & 256) ? 0u : offs[nb];          // (ablation 256: no write-out -- timing only)
+            const uint32_t nv = KB_ABL(plan, 256) ? 0u : offs[nb];          // (ablation 256: no write-out -- timing only)
             if constexpr (KW == 2) {
                 KbEnt2 *dst = (KbEnt2 *)s.tmp + slab * (uint64_t)SLAB;
                 for (uint32_t i = threadIdx.x; i < nv; i += NT) dst[i] = s2[i];
@@ -637,7 +646,7 @@ __device__ __forceinline__ void kb_sort_piece(const KbPlan &plan, const KbScratc
                     do { ++cr; cnx = rpre[cr + 1]; } while (e >= cnx);
                     cs = rsrc[cr];
                 }
-                const unsigned long long src = (plan.dbg & 256) ? ((cs + e) & 0x3FFFFull) : cs + e;      // (ablation 256: gather from 2 MB, L2 resident -- timing only)
+                const unsigned long long src = KB_ABL(plan, 256) ? ((cs + e) & 0x3FFFFull) : cs + e;      // (ablation 256: gather from 2 MB, L2 resident -- timing only)
                 if constexpr (KW == 2) { const KbEnt2 v = tmp2[src]; klo[q] = v.lo; khi[q] = v.hi; }
                 else klo[q] = s.tmp[src];
             }
@@ -651,7 +660,7 @@ __device__ __forceinline__ void kb_sort_piece(const KbPlan &plan, const KbScratc
             const uint32_t i = wbase + 64 * q;
             if (i < len) {
                 const uint32_t f = kb_fine(plan, klo[q]);               // the entry is the hash
-                if (plan.dbg & 1024) { atomicAdd(&hist[f], 1u); br[q] = f << 16; }       // (ablation 1024: no ranks -- timing only)
+                if (KB_ABL(plan, 1024)) { atomicAdd(&hist[f], 1u); br[q] = f << 16; }       // (ablation 1024: no ranks -- timing only)
                 else br[q] = (f << 16) | atomicAdd(&hist[f], 1u);
             }
         }
@@ -682,7 +691,7 @@ __device__ __forceinline__ void kb_sort_piece(const KbPlan &plan, const KbScratc
     }
     __syncthreads();
     KB_T(s.trash, 6);                                                   // scatter
-    if (plan.dbg & 512) return;                                         // (ablation 512: no write-out -- timing only)
+    if (KB_ABL(plan, 512)) return;                                         // (ablation 512: no write-out -- timing only)
     if constexpr (KW == 2) {
         // the sorted piece is stored as piece-local structure of arrays -- len h words, then len hi
         // words, in the same 16 * len bytes -- because kernel C's gathers run faster on two 8-byte
@@ -1171,6 +1180,7 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
     const uint64_t slot0 = bucket << plan.bucket_bits;        // first slot of the bucket in HBM
     if (threadIdx.x == 0) { sh_failed = 0; sh_claimed = 0; }
     bool failed = false;
+    KB_T_INIT;
     if (table_nonempty) {
         for (uint32_t i = threadIdx.x; i < B; i += CT) {
             tlo[i] = t.lo[slot0 + i];
@@ -1191,7 +1201,9 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
             ((uint2 *)tcnt)[i] = uint2{0u, 0u};
         }
     }
+    KB_T(s.trash, 30);                                        // slice initialised (or its loads issued)
     const uint32_t n_runs = ri.setup(plan, s, c);             // (barrier inside)
+    KB_T(s.trash, 31);                                        // pass descriptors
 
     constexpr uint32_t WQ = QCAP / (CT / 64);
     uint64_t *wqk = qk + (threadIdx.x >> 6) * WQ;
@@ -1209,7 +1221,9 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
         uint32_t len = 0, hioff = 0; unsigned long long first = 0;
         if (threadIdx.x < RUNS && rb + threadIdx.x < n_runs) ri.locate<KW>(plan, s, f, rb + threadIdx.x, first, len, hioff);
         uint32_t total = 0;
+        KB_T(s.trash, 32);                                    // run bounds requested
         const uint32_t ex = kb_block_exscan(len, wsum, &total);
+        KB_T(s.trash, 33);                                    // ... arrived, scanned
         if constexpr (VAR == 2 && MODE == KB_MODE_INSERT) {
             // A heavy bucket (a few keys of enormous multiplicity) is not for ONE workgroup: it is left untouched here, as
             // a failed bucket would be, and KB_HV_SLICES workgroups share its runs afterwards (kb_heavy_slice_kernel).
@@ -1280,7 +1294,7 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
                         do { ++cr; cpf = cnx; cnx = rpw[cr + 2]; } while (ei >= cnx);
                         cf = run_first[cr];
                     }
-                    bklo[q] = s.ent[(plan.dbg & 256) ? ((cf + (ei - cpf)) & 0x3FFFFull) : cf + (ei - cpf)];      // (ablation 256: entries from 2 MB -- timing only)
+                    bklo[q] = s.ent[KB_ABL(plan, 256) ? ((cf + (ei - cpf)) & 0x3FFFFull) : cf + (ei - cpf)];      // (ablation 256: entries from 2 MB -- timing only)
                 }
             }
           } else {
@@ -1339,6 +1353,11 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
                 }
             }
           }
+#ifdef KB_TIMING
+          KB_T(s.trash, 34);                                  // run table in LDS, entry loads issued
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          KB_T(s.trash, 35);                                  // entries arrived
+#endif
           if constexpr (KW == 1) {
             constexpr int G = 4;                                 // keys resolved together: G * KB_C_LA LDS reads in flight
 #pragma unroll
@@ -1399,6 +1418,7 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
                     }
                 }
             }
+            KB_T(s.trash, 36);                                // lookahead resolve
             // drain this wave's queue: dense probing, one queued key per lane (wave-private: no barrier)
             {
                 const uint32_t nq = wq_n < WQ ? wq_n : WQ;
@@ -1483,7 +1503,9 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
             }
           }
         }
+        KB_T(s.trash, 37);                                    // queue drained
         __syncthreads();       // run_pref / run_first are rewritten by the next round
+        KB_T(s.trash, 38);                                    // the other waves
     }
     if (failed) atomicOr(&sh_failed, 1u);
     if (claimed) atomicAdd(&sh_claimed, claimed);
@@ -1509,7 +1531,7 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
     // the value it had in HBM: saturate those (Jellyfish's 4-byte counter).
     // two slots per lane and step: 16-byte LDS reads and HBM stores for the keys, 8-byte ones for the counts
     // (slot0 is a multiple of B, B is even: everything stays aligned)
-    if (plan.dbg & 512) return;                                         // (ablation 512: no write-back -- timing only)
+    if (KB_ABL(plan, 512)) return;                                         // (ablation 512: no write-back -- timing only)
     for (uint32_t i = threadIdx.x; i < B / 2; i += CT) {
         if constexpr (MODE == KB_MODE_INSERT) {
             ((ulonglong2 *)(t.lo + slot0))[i] = ((const ulonglong2 *)tlo)[i];
@@ -1525,6 +1547,10 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
     }
     if (threadIdx.x == 0 && sh_claimed)
         atomicAdd(&ctl->distinct[(bucket % KDF_SHARDS) * 16], (unsigned long long)sh_claimed);
+#ifdef KB_TIMING
+    KB_T(s.trash, 39);                                        // write-back issued
+    if (threadIdx.x == 0) atomicAdd((unsigned long long *)&s.trash[8 + 40], 1ull);
+#endif
 }
 
 // Replay of the buckets kernel C flagged (s.failed): their entries go through the global-atomic path into table t,

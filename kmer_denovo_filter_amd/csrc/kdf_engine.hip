@@ -792,8 +792,8 @@ static int table_rehash(kdf_engine *h, uint32_t new_log2);
 // the small device arrays of the binned path, allocated once per engine; fills the pointers of `s` from the engine's buffers
 static int kb_scratch(kdf_engine *h, KbScratch &s) {
     if (!h->kb_small) {
-        HIPCHK(h, hipMalloc((void **)&h->kb_small, (16 + 32) * 8));
-        HIPCHK(h, hipMemsetAsync(h->kb_small, 0, (16 + 32) * 8, h->stream));
+        HIPCHK(h, hipMalloc((void **)&h->kb_small, (16 + 64) * 8));
+        HIPCHK(h, hipMemsetAsync(h->kb_small, 0, (16 + 64) * 8, h->stream));
         HIPCHK(h, hipHostMalloc((void **)&h->kb_totals_host, 16 * 8));
         HIPCHK(h, hipMalloc((void **)&h->kb_pass, sizeof(KbPass) * KB_MAX_PASS));
     }
@@ -2166,7 +2166,7 @@ int kdf_get_stat(kdf_engine *h, const char *name, int64_t *value) {
     else if (n == "bucket_bits") *value = h->t.bucket_bits;
     else if (n.rfind("trash", 0) == 0 && n.size() > 5 && h->kb_small) {          // (variant builds with -DKB_TIMING: phase cycle sums)
         const int i = atoi(n.c_str() + 5);
-        if (i < 0 || i >= 32) return fail(h, KDF_ERR_INVALID, "kdf_get_stat: trash0..trash31");
+        if (i < 0 || i >= 64) return fail(h, KDF_ERR_INVALID, "kdf_get_stat: trash0..trash63");
         unsigned long long v = 0;
         HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, hipMemcpy(&v, h->kb_small + 16 + i, 8, hipMemcpyDeviceToHost));

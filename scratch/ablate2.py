@@ -1,4 +1,5 @@
-"""stage times of the bench pass under ablation flags (WRONG results: timing only).  64 = one-piece-per-workgroup piece sort;
+"""stage times of the bench pass under ablation flags (WRONG results: timing only; needs a variant build with -DKB_ABLATE:
+scratch/build_variant.sh abl -DKB_ABLATE, then copy scratch/variants/libkdf_abl.so over kmer_denovo_filter_amd/libkdf.so).  64 = one-piece-per-workgroup piece sort;
 256 = A without write-out / B gather from 8 KB / C entries from 8 KB; 512 = B without write-out / C without write-back;
 1024 = A and B without rank return values"""
 import sys, time, torch

@@ -42,7 +42,7 @@ pipeline = cfg.get("count_path", "binned")
 wide = cfg["k"] > 32
 # prefixes of the kernels of one count pass, per pipeline
 names = {
-    "binned": ("kb_slabsort_kernel<", "kb_groupsum_kernel", "kb_binscan_kernel<", "kb_binfirst_kernel", "kb_piecesort_kernel<",
+    "binned": ("kb_slabsort_kernel<", "kb_groupsum_kernel", "kb_binscan_kernel<", "kb_binfirst_kernel", "kb_piecesort_kernel<", "kb_piecesort_pipe_kernel<",
                "kb_piecesort_more_kernel<", "kb_bucket_kernel<", "kb_heavy_slice_kernel", "kb_heavy_combine_kernel", "kb_replay_kernel<"),
 }.get(pipeline, ("kdf_stream_kernel<",))
 rows, total = [], 0.0
@@ -62,7 +62,7 @@ summary = {
     "hbm_bytes_per_window": total / n_entries,
     "kernels": rows,
     "calibration": {
-        "kernel": "kb_piecesort_kernel<%d>" % (2 if wide else 1), "known_read_bytes": n_entries * (16 if wide else 8),
+        "kernel": "kb_piecesort_pipe_kernel<%d>" % (2 if wide else 1), "known_read_bytes": n_entries * (16 if wide else 8),
         "known_write_bytes": n_entries * (16 if wide else 8),
         "note": "binned pipeline: known = one entry each way (plus < 1 % offset tables)",
     },
