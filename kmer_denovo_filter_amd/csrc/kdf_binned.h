@@ -755,7 +755,9 @@ __device__ __forceinline__ uint32_t kb_block_exscan_lds(uint32_t v, uint32_t *ws
     }
     kb_lds_barrier();
     const uint32_t r = wsum[wave] + inc - v;
-    kb_lds_barrier();
+    kb_lds_barrier();                                  // (not needed by the pipelined piece sort, whose stages put barriers of their own before
+                                                       // wsum is written again -- but without it, and without the barrier that ends an iteration,
+                                                       // the kernel measured 4.65-4.67 against 4.59 ms: waves that stay in phase share the LDS better)
     return r;
 }
 
