@@ -1657,8 +1657,8 @@ static int add_pairs_multi(kdf_engine *h, uint32_t nseg, const uint64_t *const *
         by_width(h, [&](auto KWc) {
             constexpr int KW = decltype(KWc)::value;
             hipLaunchKernelGGL(km_bounds_kernel<KW>, pg, dim3(256), 0, h->stream, h->t, sg, nb, first, last, flag);
-            if (fresh) hipLaunchKernelGGL((km_merge_kernel<KW, true>), dim3(nb), dim3(KM_THREADS), lds_bytes, h->stream, h->t, sg, nb, first, last, flag, h->ctl);
-            else hipLaunchKernelGGL((km_merge_kernel<KW, false>), dim3(nb), dim3(KM_THREADS), lds_bytes, h->stream, h->t, sg, nb, first, last, flag, h->ctl);
+            if (fresh) hipLaunchKernelGGL((km_merge_kernel<KW, true>), dim3(nb), dim3(KM_MERGE_THREADS), lds_bytes, h->stream, h->t, sg, nb, first, last, flag, h->ctl);
+            else hipLaunchKernelGGL((km_merge_kernel<KW, false>), dim3(nb), dim3(KM_MERGE_THREADS), lds_bytes, h->stream, h->t, sg, nb, first, last, flag, h->ctl);
             hipLaunchKernelGGL(km_insert_guarded_kernel<KW>, pg, dim3(256), 0, h->stream, h->t, sg, flag, h->ctl);
             return 0;
         });

@@ -19,6 +19,9 @@
 
 #define KM_BLOCK_SLOTS 4096u              // table slots one workgroup of the dump owns (a narrow bucket, two wide ones)
 #define KM_THREADS     256
+#ifndef KM_MERGE_THREADS
+#define KM_MERGE_THREADS 512              // km_merge_kernel: threads per table bucket (256 / 512 / 1024: a fresh owner table 5.3 / 4.6 / 5.3 ms)
+#endif
 #define KM_SPT         (KM_BLOCK_SLOTS / KM_THREADS)     // slots per thread
 #define KM_SUB_BITS    6                  // hash bits below the block prefix that order the dump
 #define KM_MAX_SEGS    64
@@ -258,7 +261,7 @@ __device__ __forceinline__ int km_probe_wide_once(uint64_t *tlo, uint64_t *thi, 
 
 // one workgroup per table bucket: all segments' pairs of the bucket go in through LDS
 template <int KW, bool FRESH>
-__global__ __launch_bounds__(KM_THREADS) void km_merge_kernel(KdfTable t, KmSegs sg, uint32_t nb, const uint32_t *__restrict__ first,
+__global__ __launch_bounds__(KM_MERGE_THREADS) void km_merge_kernel(KdfTable t, KmSegs sg, uint32_t nb, const uint32_t *__restrict__ first,
                                                               const uint32_t *__restrict__ last, const uint32_t *__restrict__ flag, KdfCtl *ctl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t B = 1u << t.bucket_bits, bmask = B - 1;
@@ -266,7 +269,9 @@ __global__ __launch_bounds__(KM_THREADS) void km_merge_kernel(KdfTable t, KmSegs
     uint64_t *thi = KW == 2 ? tlo + B : nullptr;
     uint32_t *tcnt = (uint32_t *)(smem + (size_t)B * 8 * KW);
     __shared__ uint32_t sh_tot, sh_claimed, sh_failed;
-    __shared__ uint32_t sf[KM_MAX_SEGS], sl_[KM_MAX_SEGS];
+    __shared__ uint32_t sf[KM_MAX_SEGS], sl_[KM_MAX_SEGS], spre[KM_MAX_SEGS + 1];
+    __shared__ const uint64_t *sp_lo[KM_MAX_SEGS], *sp_hi[KM_MAX_SEGS];
+    __shared__ const uint32_t *sp_cnt[KM_MAX_SEGS];
     const uint32_t tid = threadIdx.x;
     // an XCD takes a contiguous eighth of the buckets (workgroups are dealt to the XCDs round robin): the segments are
     // in bucket order, so its L2 sees each segment as one forward stream
@@ -278,21 +283,27 @@ __global__ __launch_bounds__(KM_THREADS) void km_merge_kernel(KdfTable t, KmSegs
     if (tid < sg.nseg && !bad) {
         const uint32_t a = first[(size_t)tid * nb + bucket], b = last[(size_t)tid * nb + bucket];
         sf[tid] = a; sl_[tid] = b;
+        sp_lo[tid] = sg.lo[tid]; sp_hi[tid] = sg.hi[tid]; sp_cnt[tid] = sg.cnt[tid];
         if (b > a) atomicAdd(&sh_tot, b - a);
     }
     __syncthreads();
+    if (tid == 0 && !bad) {                                     // where every segment's pairs start in the bucket's flat list
+        uint32_t acc = 0;
+        for (uint32_t s = 0; s < sg.nseg; ++s) { spre[s] = acc; acc += sl_[s] > sf[s] ? sl_[s] - sf[s] : 0u; }
+        spre[sg.nseg] = acc;
+    }
     const uint32_t tot = sh_tot;
     if (!FRESH && tot == 0) return;
     const uint64_t base = (uint64_t)bucket << t.bucket_bits;
     if (FRESH && tot == 0) {                                    // the deferred clear of an empty bucket
-        for (uint32_t j = tid * 2; j < B; j += KM_THREADS * 2) {
+        for (uint32_t j = tid * 2; j < B; j += KM_MERGE_THREADS * 2) {
             *(ulonglong2 *)&t.lo[base + j] = make_ulonglong2(KDF_EMPTY, KDF_EMPTY);
             if (KW == 2) *(ulonglong2 *)&t.hi[base + j] = make_ulonglong2(KDF_EMPTY, KDF_EMPTY);
             *(uint2 *)&t.cnt[base + j] = make_uint2(0u, 0u);
         }
         return;
     }
-    for (uint32_t j = tid * 2; j < B; j += KM_THREADS * 2) {
+    for (uint32_t j = tid * 2; j < B; j += KM_MERGE_THREADS * 2) {
         if (FRESH) {
             *(ulonglong2 *)&tlo[j] = make_ulonglong2(KDF_EMPTY, KDF_EMPTY);
             if (KW == 2) *(ulonglong2 *)&thi[j] = make_ulonglong2(KDF_EMPTY, KDF_EMPTY);
@@ -305,27 +316,43 @@ __global__ __launch_bounds__(KM_THREADS) void km_merge_kernel(KdfTable t, KmSegs
     }
     __syncthreads();
     uint32_t claimed = 0; bool failed = false;
-    for (uint32_t s = 0; s < sg.nseg; ++s) {
-        const uint32_t a = sf[s], e = sl_[s];
-        if (e <= a) continue;
-        const uint64_t *klo = sg.lo[s], *khi = sg.hi[s];
-        const uint32_t *kc = sg.cnt[s];
-        for (uint32_t i0 = a; i0 < e; i0 += KM_THREADS) {       // (wave-uniform trip count: the wide retry loop needs whole waves)
-            const uint32_t i = i0 + tid;
-            bool todo = i < e;
-            uint64_t lo = KDF_EMPTY, hi = 0; uint32_t add = 0;
-            if (todo) { lo = klo[i]; if (KW == 2) hi = khi[i]; add = kc ? kc[i] : 0u; }
-            const bool absent = KW == 1 ? lo == KDF_EMPTY : hi == KDF_EMPTY;     // (tested on the key as it arrived)
-            lo = kdf_hash(lo, KW == 2 ? hi & ~KDF_PENDING : 0);                  // the table holds stored forms
-            const uint32_t sl = (uint32_t)kdf_home(t, lo) & bmask;
+    // The bucket's pairs of ALL segments as one flat list: a thread takes entries tid, tid + KM_MERGE_THREADS, ... and has KM_U of
+    // them in flight.  (Segment after segment, as rounds 2-3 did it, is one global latency per segment for ~130 pairs
+    // each at world 8: the owner merge ran at 37 G pairs/s against kernel C's 264 G entries/s.)
+    constexpr int KM_U = 4;
+    const uint32_t nseg = sg.nseg;
+    for (uint32_t p0 = 0; p0 < tot; p0 += KM_MERGE_THREADS * KM_U) {  // (wave-uniform trip count: the wide retry loop needs whole waves)
+        uint64_t lo[KM_U], hi[KW == 2 ? KM_U : 1]; uint32_t add[KM_U]; bool todo[KM_U];
+#pragma unroll
+        for (int u = 0; u < KM_U; ++u) {
+            const uint32_t p = p0 + u * KM_MERGE_THREADS + tid;
+            todo[u] = p < tot;
+            lo[u] = KDF_EMPTY; add[u] = 0; if constexpr (KW == 2) hi[u] = 0;
+            if (todo[u]) {
+                uint32_t a = 0, b = nseg;                        // largest a with spre[a] <= p
+                while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (spre[m] <= p) a = m; else b = m; }
+                const uint32_t i = sf[a] + (p - spre[a]);
+                lo[u] = sp_lo[a][i];
+                if constexpr (KW == 2) hi[u] = sp_hi[a][i];
+                const uint32_t *kc = sp_cnt[a];
+                add[u] = kc ? kc[i] : 0u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < KM_U; ++u) {
+            if (p0 + u * KM_MERGE_THREADS >= tot) break;               // (uniform)
+            const bool absent = KW == 1 ? lo[u] == KDF_EMPTY : hi[KW == 2 ? u : 0] == KDF_EMPTY;     // (tested on the key as it arrived)
+            const uint64_t khi = KW == 2 ? hi[KW == 2 ? u : 0] & ~KDF_PENDING : 0;
+            const uint64_t h = kdf_hash(lo[u], khi);             // the table holds stored forms
+            const uint32_t sl = (uint32_t)kdf_home(t, h) & bmask;
             if (KW == 1) {
-                if (todo && !absent) km_probe_narrow(tlo, tcnt, bmask, lo, add, sl, claimed, failed);
+                if (todo[u] && !absent) km_probe_narrow(tlo, tcnt, bmask, h, add[u], sl, claimed, failed);
             } else {
-                todo = todo && !absent;
-                while (__any(todo)) {
-                    if (todo) {
-                        const int res = km_probe_wide_once(tlo, thi, tcnt, bmask, lo, hi & ~KDF_PENDING, add, sl, claimed);
-                        if (res != 2) { todo = false; if (res == 1) failed = true; }
+                bool td = todo[u] && !absent;
+                while (__any(td)) {
+                    if (td) {
+                        const int res = km_probe_wide_once(tlo, thi, tcnt, bmask, h, khi, add[u], sl, claimed);
+                        if (res != 2) { td = false; if (res == 1) failed = true; }
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -337,7 +364,7 @@ __global__ __launch_bounds__(KM_THREADS) void km_merge_kernel(KdfTable t, KmSegs
     if ((tid & 63) == 0 && claimed) atomicAdd(&sh_claimed, claimed);
     if (failed) sh_failed = 1;
     __syncthreads();
-    for (uint32_t j = tid * 2; j < B; j += KM_THREADS * 2) {
+    for (uint32_t j = tid * 2; j < B; j += KM_MERGE_THREADS * 2) {
         *(ulonglong2 *)&t.lo[base + j] = *(const ulonglong2 *)&tlo[j];
         if (KW == 2) *(ulonglong2 *)&t.hi[base + j] = *(const ulonglong2 *)&thi[j];
         *(uint2 *)&t.cnt[base + j] = *(const uint2 *)&tcnt[j];
