@@ -743,14 +743,20 @@ static KbPlan kb_make_plan(const kdf_engine *h, const KdfTable &t) {
     KbPlan p{};
     p.log2cap = t.log2cap; p.bucket_bits = t.bucket_bits;
     const uint32_t nb_bits = t.log2cap - t.bucket_bits;
-    // prefer an 8-bit fine radix and <= 9 coarse bits (longest runs); widen only
-    // when the table has more buckets than that resolves
+    // 8 + 8 bits while that resolves the table; then the FINE radix widens first (8 + 9: the piece sort gathers 512-byte
+    // runs instead of 256-byte ones and ranks into 512 bins; the bucket kernel pays with twice the runs of half the
+    // length -- measured at bench size, 9 + 8 / 8 + 9 / 10 + 7: piece sort 4.74 / 4.21 / 5.88 ms, bucket kernel 4.40 / 4.79 / 4.20,
+    // pass 12.35 / 12.16 / 13.60), then the coarse one (9 + 9, 10 + 9)
     p.c2 = std::min<uint32_t>(KB_F_BITS, nb_bits);
-    p.c1 = std::min<uint32_t>(9, nb_bits - p.c2);
-    if (p.c1 + p.c2 < nb_bits) p.c2 = std::min<uint32_t>(9, nb_bits - p.c1);               // fine runs halve: still >= 256 B
+    p.c1 = std::min<uint32_t>(8, nb_bits - p.c2);
+    if (p.c1 + p.c2 < nb_bits) p.c2 = std::min<uint32_t>(9, nb_bits - p.c1);               // fine runs halve: still >= 240 B
     if (p.c1 + p.c2 < nb_bits) p.c1 = std::min<uint32_t>(KB_C1_MAX, nb_bits - p.c2);      // coarse runs halve
     // (beyond 2^19 buckets kernel C reads every run once per sub-bucket: 10 fine bits -- 16-entry runs -- measured worse,
     // 9.65 against 8.86 ms per 10 M reads into 2^32 slots)
+    if (const char *ev = getenv("KDF_C1")) {                       // (experiments: another split of the same bits)
+        const uint32_t c1 = (uint32_t)atoi(ev);
+        if (c1 <= KB_C1_MAX && c1 <= nb_bits && nb_bits - c1 <= KB_F_BITS_MAX) { p.c1 = c1; p.c2 = nb_bits - c1; }
+    }
     p.sub_bits = nb_bits - p.c1 - p.c2;
     p.off_stride = (1u << p.c2) + 1;
     // Slabs per group: a piece (bin x group) is ~0.93 CHUNK entries.  Windows per stream position: what this engine has
