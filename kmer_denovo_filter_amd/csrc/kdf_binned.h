@@ -558,8 +558,10 @@ __global__ __launch_bounds__(KB_THREADS) void kb_binfirst_kernel(KbPlan plan, Kb
     for (uint32_t w = 0; w < KB_THREADS / 64; ++w) { const unsigned long long v = esum[w * 64 + 63]; if (w < (threadIdx.x >> 6)) wpre += v; tot_e += v; }
     if (threadIdx.x < nb) {
         P->binrow_first[threadIdx.x] = ex; P->binent_first[threadIdx.x] = wpre + inc - e;
-        // skewed: one coarse bin holds more than twice its share (a uniform hash keeps the bins within a few per cent)
-        if (nb > 1 && e * (unsigned long long)nb > 2 * tot_e + 65536ull * nb) s.totals[7] = 1ull;
+        // skewed: one coarse bin holds 6 % + 65 536 entries more than its share (a uniform hash keeps a bin of n entries
+        // within a few sqrt(n) of it).  (Rounds 2-3 asked for TWICE the share, which a table with four coarse bins cannot
+        // show unless one key is half of all windows.)
+        if (nb > 1 && e * (unsigned long long)nb > tot_e + tot_e / 16 + 65536ull * nb) s.totals[7] = 1ull;
     }
     if (threadIdx.x == 0) {
         P->binrow_first[nb] = tot_r; P->binent_first[nb] = tot_e;
@@ -1226,7 +1228,7 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
         KB_T(s.trash, 32);                                    // run bounds requested
         const uint32_t ex = kb_block_exscan(len, wsum, &total);
         KB_T(s.trash, 33);                                    // ... arrived, scanned
-        if constexpr (VAR == 2 && MODE == KB_MODE_INSERT) {
+        if constexpr (VAR == 2) {
             // A heavy bucket (a few keys of enormous multiplicity) is not for ONE workgroup: it is left untouched here, as
             // a failed bucket would be, and KB_HV_SLICES workgroups share its runs afterwards (kb_heavy_slice_kernel).
             if (rb == 0 && total > KB_C_HEAVY && s.hv_ctr && plan.sub_bits == 0) {   // (the host launches the heavy kernels under the same conditions)
@@ -1240,7 +1242,8 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
                 __syncthreads();
                 if (threadIdx.x == 0) sh_failed = 0;
                 if (taken) {
-                    if (!table_nonempty)
+                    // (count --if: the keys stay where they are, kb_heavy_filtered_kernel adds to the counts in HBM)
+                    if (MODE == KB_MODE_INSERT && !table_nonempty)
                         for (uint32_t i = threadIdx.x; i < B; i += CT) {
                             t.lo[slot0 + i] = KDF_EMPTY; t.cnt[slot0 + i] = 0;
                             if constexpr (KW == 2) t.hi[slot0 + i] = KDF_EMPTY;
@@ -1758,6 +1761,68 @@ __global__ __launch_bounds__(256) void kb_heavy_combine_kernel(KbPlan plan, KbSc
         if constexpr (KW == 2) t.hi[slot0 + i] = thi[i];
     }
     if (tid == 0 && sh_claimed) atomicAdd(&ctl->distinct[(bucket % KDF_SHARDS) * 16], (unsigned long long)sh_claimed);
+}
+
+// Heavy buckets of a skewed `count --if` flush.  Every window of the parents' reads is partitioned, also the ones whose key
+// is not in the filter: a homopolymer k-mer is 1.4 % of ALL windows of a repeat-rich genome, and all of them arrive at one
+// bucket -- for one workgroup to look them up one after the other (a 30x human parent: ~10^9 entries).  The bucket's keys do
+// not change in this mode, so KB_HV_SLICES workgroups simply share its runs, each with a read-only copy of the key slice and
+// private counts in LDS, and add what they counted to the counts in HBM (saturating; a few slots per workgroup).
+template <int KW>
+__global__ __launch_bounds__(256) void kb_heavy_filtered_kernel(KbPlan plan, KbScratch s, KdfTable t) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (!s.hv_ctr) return;
+    const uint32_t nh = min(s.hv_ctr[0], KB_HV_MAX), h = blockIdx.y, slice = blockIdx.x;
+    if (h >= nh) return;
+    if (h == 0 && slice == 0 && threadIdx.x == 0) s.totals[4] = s.hv_ctr[0];
+    const uint32_t B = 1u << plan.bucket_bits, bmask = B - 1;
+    uint64_t *tlo = (uint64_t *)smem;
+    uint64_t *thi = KW == 2 ? tlo + B : nullptr;
+    uint32_t *tcnt = (uint32_t *)(smem + (size_t)B * 8 * KW);
+    KbRunIndex ri; ri.bind(smem + (size_t)B * (8 * KW + 4));
+    const uint32_t tid = threadIdx.x;
+    const uint64_t bucket = s.hv_bucket[h];
+    const uint64_t slot0 = bucket << plan.bucket_bits;
+    for (uint32_t i = tid; i < B; i += 256) { tlo[i] = t.lo[slot0 + i]; if constexpr (KW == 2) thi[i] = t.hi[slot0 + i]; tcnt[i] = 0; }
+    const uint32_t c = (uint32_t)(bucket >> plan.c2), f = (uint32_t)(bucket & ((1u << plan.c2) - 1));
+    const uint32_t n_runs = ri.setup(plan, s, c);               // (barrier inside)
+    const uint32_t hsh_r = 64 - plan.log2cap;
+    for (uint32_t r = slice; r < n_runs; r += KB_HV_SLICES) {
+        unsigned long long first; uint32_t n, hioff;
+        ri.locate<KW>(plan, s, f, r, first, n, hioff);
+        const uint64_t *ent = s.ent + first;
+        constexpr int U = KW == 2 ? 4 : 8;
+        for (uint32_t i0 = 0; i0 < n; i0 += 256 * U) {             // whole waves: the hit counting is a wave operation
+            uint64_t keys[U], his[KW == 2 ? U : 1];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t i = i0 + u * 256 + tid;
+                keys[u] = i < n ? ent[i] : 0;
+                if constexpr (KW == 2) his[u] = i < n ? ent[i + hioff] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (i0 + u * 256 >= n) break;                      // (uniform)
+                const bool todo = i0 + u * 256 + tid < n;
+                const uint64_t key = keys[u];
+                uint32_t sl = (uint32_t)(key >> hsh_r) & bmask;
+                // read-only linear probe: the key, or the first empty slot (absent).  Almost every entry of a heavy bucket
+                // is THE heavy key: found in its home slot, or absent at the first look.
+                bool hit = false;
+                if (todo) {
+                    for (uint32_t p_ = 0; p_ <= bmask; ++p_) {
+                        const uint64_t cur = tlo[sl];
+                        if (KW == 1 ? cur == KDF_EMPTY : thi[sl] == KDF_EMPTY) break;
+                        if (cur == key && (KW == 1 || thi[sl] == his[KW == 2 ? u : 0])) { hit = true; break; }
+                        sl = (sl + 1) & bmask;
+                    }
+                }
+                kb_count_hits<true>(tcnt, sl, hit);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < B; i += 256) { const uint32_t a = tcnt[i]; if (a) kdf_sat_add(&t.cnt[slot0 + i], a); }
 }
 
 // ---------------------------------------------------------------------------

@@ -790,6 +790,7 @@ static int kb_set_lds_attrs(kdf_engine *h, size_t a, size_t b, size_t c, size_t 
 #undef KB_SETV
     HIPCHK(h, hipFuncSetAttribute((const void *)kb_heavy_slice_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hv));
     HIPCHK(h, hipFuncSetAttribute((const void *)kb_heavy_combine_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hv));
+    HIPCHK(h, hipFuncSetAttribute((const void *)kb_heavy_filtered_kernel<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hv));
     return KDF_OK;
 }
 
@@ -1015,7 +1016,7 @@ static int kb_flush_ring(kdf_engine *h) {
         hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, h->stream); sev.push_back(e);
     }
     if (plan.dbg & 2048) return kb_ring_reset(h);                 // (ablation: the partition passes are timed alone, what they wrote is dropped)
-    const bool heavy = skewed && !filtered && s.hv_ctr && plan.sub_bits == 0;
+    const bool heavy = skewed && s.hv_ctr && plan.sub_bits == 0;
     if (heavy) {
         HIPCHK(h, hipMemsetAsync(s.hv_ctr, 0, (4 + 3 * KB_HV_MAX) * 4, h->stream));
     }
@@ -1033,7 +1034,10 @@ static int kb_flush_ring(kdf_engine *h) {
     if (heavy) {
         // the buckets the skewed instantiation left aside
         const size_t lds_h = ((size_t)(8 * h->kw + 4) << plan.bucket_bits) + KB_RI_LDS_BYTES;
-        if (h->kw == 1) {
+        if (filtered) {                                            // the keys stay put: the slices add to the counts in HBM
+            if (h->kw == 1) hipLaunchKernelGGL(kb_heavy_filtered_kernel<1>, dim3(KB_HV_SLICES, KB_HV_MAX), dim3(256), lds_h, h->stream, plan, s, h->t);
+            else hipLaunchKernelGGL(kb_heavy_filtered_kernel<2>, dim3(KB_HV_SLICES, KB_HV_MAX), dim3(256), lds_h, h->stream, plan, s, h->t);
+        } else if (h->kw == 1) {
             hipLaunchKernelGGL(kb_heavy_slice_kernel<1>, dim3(KB_HV_SLICES, KB_HV_MAX), dim3(256), lds_h, h->stream, plan, s);
             hipLaunchKernelGGL(kb_heavy_combine_kernel<1>, dim3(KB_HV_MAX), dim3(256), lds_h, h->stream, plan, s, h->t, h->ctl, nonempty);
         } else {

@@ -114,3 +114,44 @@ def test_repeat_rich_genome_at_scale_binned_equals_direct():
             dumps.append((lo, cnt, windows))
     assert dumps[0][2] == dumps[1][2]
     assert dumps[0][0].numel() == dumps[1][0].numel() and torch.equal(dumps[0][0], dumps[1][0]) and torch.equal(dumps[0][1], dumps[1][1])
+
+
+@pytest.mark.parametrize("k", [31, 63])
+def test_binned_count_if_splits_heavy_buckets(oracle, k):
+    """`count --if` through the binned pipeline (what a whole-genome filter takes: too big for the sieve) on parents whose
+    reads are full of homopolymer and microsatellite windows: EVERY window is partitioned, so the repeats' buckets are as
+    heavy as in a full count whether or not their k-mers are in the filter.  The skew instantiation leaves such a bucket to
+    kb_heavy_filtered_kernel (32 workgroups share its runs over a read-only copy of the keys); the per-key counts must equal
+    the oracle's with the repeat k-mers in the filter and without them."""
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    fl = lambda n: acgt[rng.integers(0, 4, n)].tobytes().decode()
+    longer = 0 if k <= 32 else 40
+    heavy = []
+    for _ in range(60_000):
+        heavy.append(fl(int(rng.integers(5, 40))) + "A" * int(rng.integers(40 + longer, 100 + longer)) + fl(int(rng.integers(5, 30))))
+    for _ in range(30_000):
+        heavy.append(fl(10) + "CA" * int(rng.integers(25 + longer // 2, 50 + longer // 2)) + fl(12))
+    reads = heavy + [fl(int(rng.integers(100, 151))) for _ in range(40_000)]
+    rng.shuffle(reads)
+    lo, hi, cnt = oracle.OracleTable(k, 1 << 12).count_reads(reads[::2], threads=8).export_ge(0)     # "child": every other read
+    top = np.argsort(cnt)[-4:]                                   # the repeat k-mers
+    assert int(cnt[top[-1]]) > 200_000
+    light = np.ones(len(lo), bool); light[top] = False
+    st = ReadStream.from_strings(reads)
+    for name, sel in (("with the repeats", np.arange(len(lo))[::3].tolist() + top.tolist()), ("without them", np.flatnonzero(light)[::3].tolist())):
+        sel = np.unique(np.asarray(sel))
+        flo, fhi = lo[sel], hi[sel]
+        ot = oracle.OracleTable(k, 1 << 12).load_filter(flo, fhi).count_reads_filtered(reads)
+        want = ot.query(flo, fhi)
+        with KmerEngine(k, capacity_hint=1 << 22) as e:
+            e.load_filter(flo, fhi if k > 32 else None)
+            e.set_option("force_path", 2)
+            e.count_filtered(st)                                 # (the first flush of an engine already knows the skew: C is deferred)
+            got = e.query(flo, fhi if k > 32 else None)
+            np.testing.assert_array_equal(got, want, err_msg=name)
+            assert e.get_stat("heavy_buckets") > 0, "no bucket was split: the test does not reach kb_heavy_filtered_kernel"
+            e.reset_counts()
+            e.count_filtered(st); e.count_filtered(st)           # twice more into the live counts
+            np.testing.assert_array_equal(e.query(flo, fhi if k > 32 else None), want * 2, err_msg=name + " (x2)")
