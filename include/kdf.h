@@ -103,12 +103,16 @@ int kdf_flush(kdf_engine *h);
  *            are partitioned where they lie, default 2^28);
  *            "hash_shift" (0..8, empty table only: the home slot ignores that many top hash bits -- the table of
  *            an OWNER rank of the multi-GPU merge, see kdf_add_pairs_multi_dev; such an engine counts through the
- *            direct kernels only); "merge_min_pairs" (below this many pairs kdf_add_pairs* skips the bucket merge)
+ *            direct kernels only); "merge_min_pairs" (below this many pairs kdf_add_pairs* skips the bucket merge);
+ *            "big_bucket_log2cap" (default 32; KDF_BIG_BUCKET_LOG2CAP: tables of 2^that slots and more have buckets of
+ *            twice the slots -- an internal layout: dumps, queries and index files do not depend on it; a live table
+ *            is re-bucketed when the option changes its bucket size); "debug_flags" (experiments: 64 one piece per
+ *            workgroup in the piece sort, 2048 partition without the bucket kernel, 4096 force the skew instantiation)
  *   stats    "binned_passes" (partition passes), "flushes" (kernel C launches), "pending_passes",
  *            "pending_positions", "ring_bytes", "replayed_buckets", "heavy_buckets" (buckets of skewed flushes that
  *            were shared by several workgroups), "log2cap", "bucket_bits", "hash_shift", "defer",
  *            "last_count_path" (0 direct / 1 binned / 3 sieve), "last_merge_path" (1 LDS bucket
- *            merge, 2 global atomics) */
+ *            merge, 2 global atomics); "trash0" .. "trash63" (phase cycle sums of -DKB_TIMING variant builds) */
 int kdf_set_option(kdf_engine *h, const char *name, int64_t value);
 /* Free / total HBM of a device (hipMemGetInfo): the child-count mirror sizes "key_parts" with it. */
 int kdf_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
@@ -120,8 +124,8 @@ int kdf_get_stat(kdf_engine *h, const char *name, int64_t *value);
  * launches and the stream positions they covered since kdf_profile(h, 1). */
 int kdf_profile(kdf_engine *h, int enable);
 int kdf_profile_read(kdf_engine *h, double *kernel_ms, uint64_t *launches, uint64_t *positions);
-/* Binned passes only: summed milliseconds of the four stages (A0 histogram +
- * scans, A1 scatter, B fine sort, C bucket kernel) and the number of passes. */
+/* Binned passes only: summed milliseconds of the four stages (A slab sort, the
+ * planning kernels, B piece sort, C bucket kernel) and the number of passes. */
 int kdf_profile_stages(kdf_engine *h, double *stage_ms4, uint64_t *passes);
 
 /* ------------------------------------------------- count (insert) stage -- */

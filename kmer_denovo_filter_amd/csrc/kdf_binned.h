@@ -10,10 +10,12 @@
 //       again), counting-sorted in LDS by coarse bin (top c1 hash bits) and written out as ONE contiguous block,
 //       with the slab's bin offsets (a row of u16).  No histogram pass, no global cursors, no partial cache lines.
 //   P   kb_groupsum_kernel / kb_plan_kernel: G consecutive slabs form a GROUP; the entries of bin c in group g are a
-//       PIECE of ~0.93 CHUNK entries (more under skew: then several pieces).  Exact piece sizes from the offset rows
+//       PIECE of ~0.95 CHUNK entries (more under skew: then several pieces).  Exact piece sizes from the offset rows
 //       (190 MB for 1.5 G positions), piece -> row of the offset table, compact piece -> ring position, per-bin piece lists.
-//   B   kb_piecesort_kernel: one workgroup per piece gathers its runs (one per slab of the group), sorts them in LDS
-//       by the next c2 hash bits and appends the sorted piece + its offset row to the engine's entry RING.
+//   B   kb_piecesort_pipe_kernel: a piece's runs (one per slab of the group) are gathered, sorted in LDS by the next c2
+//       hash bits and appended, with the piece's offset row, to the engine's entry RING -- by one persistent workgroup
+//       per CU that keeps four pieces in flight at different stages (kb_piecesort_kernel: a workgroup per piece, for
+//       comparison; kb_piecesort_more_kernel: the further pieces of a skewed pair).
 //
 // Rounds 1-2 read the stream twice (a histogram pass A0 fixed an exact place for every (workgroup, bin) run before the
 // scatter A1 could copy its runs out bin by bin); A0 + A1 took 5.9 ms of a 14.3 ms pass.
@@ -36,8 +38,8 @@
 #include "kdf_device.h"
 
 #define KB_THREADS   1024
-#define KB_F_BITS    8                   // preferred fine radix (level 2)
-#define KB_F_BITS_MAX 9                  // used only when the table has more buckets than 2^(9 + 8)
+#define KB_F_BITS    8                   // fine radix (level 2) of tables of up to 2^16 buckets
+#define KB_F_BITS_MAX 9                  // ... of the others (kb_make_plan: 8 + 8, then 8 + 9, 9 + 9, 10 + 9 bits)
 #define KB_F         (1 << KB_F_BITS_MAX)  // LDS array size for the fine histogram
 #define KB_C1_MAX    10                  // coarse bins <= 1024
 #define KB_MAX_PASS  64                  // pending passes one kernel C can apply
