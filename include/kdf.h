@@ -107,7 +107,9 @@ int kdf_flush(kdf_engine *h);
  *            "big_bucket_log2cap" (default 32; KDF_BIG_BUCKET_LOG2CAP: tables of 2^that slots and more have buckets of
  *            twice the slots -- an internal layout: dumps, queries and index files do not depend on it; a live table
  *            is re-bucketed when the option changes its bucket size); "debug_flags" (experiments: 64 one piece per
- *            workgroup in the piece sort, 2048 partition without the bucket kernel, 4096 force the skew instantiation)
+ *            workgroup in the piece sort, 2048 partition without the bucket kernel, 4096 force the skew instantiation).
+ *            Environment, read when a partition is planned (experiments: DESIGN.md section 3.2 has what they measured):
+ *            KDF_C1 (coarse bits of the partition), KDF_PIECE_FILL (how full the pieces are planned, default 0.98)
  *   stats    "binned_passes" (partition passes), "flushes" (kernel C launches), "pending_passes",
  *            "pending_positions", "ring_bytes", "replayed_buckets", "heavy_buckets" (buckets of skewed flushes that
  *            were shared by several workgroups), "log2cap", "bucket_bits", "hash_shift", "defer",
