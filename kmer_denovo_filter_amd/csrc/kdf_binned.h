@@ -176,12 +176,22 @@ struct KbScratch {
 #define KB_C_HEAVY   65536u                          // entries (first 256 runs) from which a bucket counts as heavy: ~7x a bucket's share at bench load
 #endif
 
+// (both live in the high half of the hash -- c1 + c2 <= 19: 32-bit shifts)
+#ifndef KDF_FUNNEL64
+__device__ __forceinline__ uint32_t kb_coarse(const KbPlan &p, uint64_t h) {
+    return p.c1 ? (uint32_t)(h >> 32) >> (32 - p.c1) : 0u;
+}
+__device__ __forceinline__ uint32_t kb_fine(const KbPlan &p, uint64_t h) {
+    return p.c2 ? ((uint32_t)(h >> 32) >> (32 - p.c1 - p.c2)) & ((1u << p.c2) - 1) : 0u;
+}
+#else
 __device__ __forceinline__ uint32_t kb_coarse(const KbPlan &p, uint64_t h) {
     return p.c1 ? (uint32_t)(h >> (64 - p.c1)) : 0u;
 }
 __device__ __forceinline__ uint32_t kb_fine(const KbPlan &p, uint64_t h) {
     return p.c2 ? (uint32_t)((h >> (64 - p.c1 - p.c2)) & ((1u << p.c2) - 1)) : 0u;
 }
+#endif
 
 // Ablation flags (debug_flags 256 / 512 / 1024: a kernel without its write-out / with its gather served from L2 / without rank
 // return values -- WRONG results, timing only; scratch/ablate2.py) exist in variant builds only (-DKB_ABLATE): in the product
@@ -297,12 +307,13 @@ struct KbWindows {
     }
     __device__ __forceinline__ void key(int u, uint64_t &lo, uint64_t &hi) const {   // u: compile-time
         if constexpr (KW == 1) {
-            const uint64_t rc = ~kdf_funnel(e[0], e[1], 2 * u) & kmask;      // reverse complement: ~E (kdf_device.h)
-            const uint64_t fwd = kdf_funnel(g0, g1, 2 * (WPT - 1 - u)) & kmask;
+            static_assert(2 * (WPT - 1) < 32, "the per-window shifts fit kdf_funnel32");
+            const uint64_t rc = ~kdf_funnel32(e[0], e[1], 2 * u) & kmask;      // reverse complement: ~E (kdf_device.h)
+            const uint64_t fwd = kdf_funnel32(g0, g1, 2 * (WPT - 1 - u)) & kmask;
             lo = fwd < rc ? fwd : rc; hi = 0;
         } else {
-            const uint64_t rlo = ~kdf_funnel(e[0], e[1], 2 * u), rhi = ~kdf_funnel(e[1], e[2], 2 * u) & hmask;   // reverse complement: ~E
-            const uint64_t flo = kdf_funnel(gw[0], gw[1], 2 * (WPT - 1 - u)), fhi = kdf_funnel(gw[1], gw[2], 2 * (WPT - 1 - u)) & hmask;
+            const uint64_t rlo = ~kdf_funnel32(e[0], e[1], 2 * u), rhi = ~kdf_funnel32(e[1], e[2], 2 * u) & hmask;   // reverse complement: ~E
+            const uint64_t flo = kdf_funnel32(gw[0], gw[1], 2 * (WPT - 1 - u)), fhi = kdf_funnel32(gw[1], gw[2], 2 * (WPT - 1 - u)) & hmask;
             const bool fw = (fhi < rhi) || (fhi == rhi && flo < rlo);
             lo = fw ? flo : rlo; hi = fw ? fhi : rhi;
         }

@@ -289,6 +289,16 @@ __device__ __forceinline__ uint64_t kdf_funnel(uint64_t lo, uint64_t hi, int sh)
     return sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
 }
 
+// the same for sh in 0..31, on the 32-bit halves: two v_alignbit_b32 (full rate) where the 64-bit form above compiles to a
+// 64-bit shift (half rate), a 32-bit shift and an OR per result
+__device__ __forceinline__ uint64_t kdf_funnel32(uint64_t lo, uint64_t hi, int sh) {
+#ifdef KDF_FUNNEL64                                   // (variant builds: the 64-bit form, for same-box comparisons)
+    return kdf_funnel(lo, hi, sh);
+#endif
+    const uint32_t l0 = (uint32_t)lo, l1 = (uint32_t)(lo >> 32), h0 = (uint32_t)hi;
+    return ((uint64_t)__builtin_amdgcn_alignbit(h0, l1, (uint32_t)sh) << 32) | __builtin_amdgcn_alignbit(l1, l0, (uint32_t)sh);
+}
+
 // canonical key of the window starting at local position p (0..63), narrow.
 __device__ __forceinline__ uint64_t kdf_window_narrow(const uint64_t (&w)[3], int p, int k, uint64_t kmask) {
     const int word = p >> 5, sh = (p & 31) * 2;
