@@ -116,7 +116,7 @@ class KmerEngine:
         return list(ms), n.value
 
     _PATHS = ("direct", "binned", "-", "sieve")
-    _STAGES = ["kb_slabsort_kernel", "kb_groupsum+kb_plan", "kb_piecesort_kernel", "kb_bucket_kernel"]
+    _STAGES = ["kb_slabsort_kernel", "kb_groupsum+kb_plan", "kb_piecesort_pipe_kernel", "kb_bucket_kernel"]
 
     def last_count_path(self) -> str:
         """Which pipeline the last count call took: direct / binned / sieve."""
