@@ -345,14 +345,18 @@ __global__ __launch_bounds__(KB_A_THREADS) void kb_slabsort_kernel(
     constexpr int WPT = KbCfg<KW>::WPT, TPT = 64 / WPT, SLAB = KbCfg<KW>::SLAB, NT = KB_A_THREADS;
     constexpr uint32_t TILES_PER_SLAB = NT / TPT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t *slo = (uint64_t *)smem;                                   // [SLAB + 2]: [SLAB] = trash slot
+    uint64_t *slo = (uint64_t *)smem;                                   // [SLAB + 64]: [SLAB + lane] = the lane's trash slot
     KbEnt2 *s2 = (KbEnt2 *)smem;                                        // wide: the image holds (h, hi) pairs
-    uint32_t *hist = (uint32_t *)(smem + (size_t)(SLAB + 2) * 8 * KW);  // [bins + 1 ..]: [DUMMY] = counter of invalid windows
-    uint32_t *offs = hist + (1 << KB_C1_MAX) + 32;                      // [bins + 1 ..]: offs[DUMMY] = trash slot
+    // Invalid windows (N, read ends: 22 % of the window slots of 150 bp reads) are ranked like the others, branch-free, on
+    // DUMMY counters -- ONE PER LANE: with a single dummy counter a quarter of a wave's lanes hit the same LDS word in every
+    // rank instruction and the same trash slot in every scatter (SQ_LDS_ADDR_CONFLICT: 318 M of the kernel's 831 M active
+    // LDS cycles, profiles/r03b_lds_counters.txt).
+    uint32_t *hist = (uint32_t *)(smem + (size_t)(SLAB + 64) * 8 * KW); // [bins + 1 ..]: [DUMMY + lane] = counters of invalid windows (never read)
+    uint32_t *offs = hist + (1 << KB_C1_MAX) + 96;                      // [bins + 1 ..]: offs[DUMMY + lane] = SLAB + lane, the lane's trash slot
     constexpr int DUMMY = (1 << KB_C1_MAX) + 1;             // (index 2^c1 <= 1024 holds the slab's total)
     const int nb = 1 << plan.c1;
     for (int i = threadIdx.x; i <= DUMMY; i += NT) hist[i] = 0;
-    if (threadIdx.x == 0) offs[DUMMY] = (uint32_t)SLAB;
+    if (threadIdx.x < 64) offs[DUMMY + threadIdx.x] = (uint32_t)SLAB + threadIdx.x;
     __syncthreads();
     const uint64_t slab0 = (uint64_t)blockIdx.x * slabs_per_wg;
     if (slab0 * TILES_PER_SLAB >= n_tiles) return;                     // uniform
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(KB_A_THREADS) void kb_slabsort_kernel(
             uint64_t hsh, hi; win.stored(u, hsh, hi);
             klo[u] = hsh; if constexpr (KW == 2) khi[u] = hi;
             const bool ok = ((win.valid >> u) & 1) && (!SLICED || kdf_slice(hsh, plan.key_parts) == plan.key_part);
-            const uint32_t bin = ok ? kb_coarse(plan, hsh) : (uint32_t)DUMMY;
+            const uint32_t bin = ok ? kb_coarse(plan, hsh) : (uint32_t)DUMMY + (threadIdx.x & 63u);
             br[u] = bin << 16;
         }
         if (KB_ABL(plan, 1024)) {                                          // (ablation: counts without ranks -- WRONG results, timing only)
@@ -429,12 +433,12 @@ __global__ __launch_bounds__(KB_A_THREADS) void kb_slabsort_kernel(
         kb_lds_barrier();                                               // B2: offsets ready
         KB_T(s.trash, 13);
         {
-            // invalid windows land on the trash slot (offs[DUMMY] = SLAB, rank masked off)
+            // invalid windows land on their lane's trash slot (offs[DUMMY + lane] = SLAB + lane, rank masked off)
             uint32_t pos[WPT];
 #pragma unroll
             for (int u = 0; u < WPT; ++u) {
                 const uint32_t bin = br[u] >> 16;
-                pos[u] = offs[bin] + ((bin == (uint32_t)DUMMY) ? 0u : (br[u] & 0xFFFF));
+                pos[u] = offs[bin] + ((bin >= (uint32_t)DUMMY) ? 0u : (br[u] & 0xFFFF));
             }
 #pragma unroll
             for (int u = 0; u < WPT; ++u) {
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(KB_A_THREADS) void kb_slabsort_kernel(
         {
             uint16_t *orow = s.off + slab * (uint64_t)(nb + 1);
             for (int i = threadIdx.x; i <= nb; i += NT) { orow[i] = (uint16_t)offs[i]; hist[i] = 0; }
-            if (threadIdx.x == 0) hist[DUMMY] = 0;
+            // (the dummy counters are never read: they may run on)
         }
         // (Measured and dropped, round 3: the NEXT slab's keys computed here, between scatter and B3, with its words
         // requested before the write-out -- 3.93 against 3.15 ms at k = 31, 6.95 against 5.61 at k = 63: the key arithmetic at

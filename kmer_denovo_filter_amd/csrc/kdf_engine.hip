@@ -892,7 +892,7 @@ static int kb_partition(kdf_engine *h, const uint64_t *d_packed, const uint64_t 
     plan.dbg = h->opt_debug_flags;
     plan.n_slabs = (uint32_t)n_slabs; plan.n_groups = (uint32_t)n_groups;
     const int nb1 = 1 << KB_C1_MAX;
-    const size_t lds_a = (size_t)(SLAB + 2) * 8 * KW + (size_t)(2 * (nb1 + 32)) * 4;
+    const size_t lds_a = (size_t)(SLAB + 64) * 8 * KW + (size_t)(2 * (nb1 + 96)) * 4;
     const size_t lds_b = (size_t)CHUNK * 8 * KW + (size_t)(2 * KB_F + 32) * 4 + (size_t)KB_G_MAX * 12 + 32;
     if (!h->attrs_set[KW]) {                                   // once per engine
         const size_t lds_c = KB_C_LDS(KW, KB_BB_SMALL(KW));
