@@ -201,7 +201,7 @@ def _count_fasta_to_index(fasta_path, kmer_size, out_path, capacity_hint, cmdlin
             for batch in rd:
                 eng.count(batch)
         lo, hi, cnt = eng.export_ge(0)
-    jf_io.write_index(out_path, kmer_size, lo, hi, cnt, cmdline=cmdline)
+    jf_io.write_index_auto(out_path, kmer_size, lo, hi, cnt, cmdline=cmdline)    # (KDF_JF_FORMAT=jellyfish: a real binary/sorted file)
     return len(lo)
 
 

@@ -34,6 +34,35 @@ def test_reference_index_equals_real_jellyfish(oracle, tmp_path):
     assert _ensure_ref_jf(fa, 31, 4) == path and os.path.getmtime(path) == before
 
 
+def test_reference_index_written_as_jellyfish_is_the_real_file(tmp_path, monkeypatch):
+    """KDF_JF_FORMAT=jellyfish: `_ensure_ref_jf` writes a Jellyfish binary/sorted file (records in the order of their hash
+    position under the header's GF(2) matrix).  mini_ref.fa counted on the GPU and written under the REAL file's header
+    (hash size and matrix of `jellyfish count -m 31 -s 100M -C`) must be that file, record for record, byte for byte."""
+    import shutil
+    from kmer_denovo_filter_amd import jf_io
+    from kmer_denovo_filter_amd.core.jellyfish_wrappers import _ensure_ref_jf
+    real = os.path.join(GIAB, "mini_ref.fa.k31.jf")
+    fa = str(tmp_path / "mini_ref.fa")
+    shutil.copy(os.path.join(GIAB, "mini_ref.fa"), fa)
+    monkeypatch.setenv("KDF_JF_FORMAT", "jellyfish")
+    path = _ensure_ref_jf(fa, 31, 4)
+    header, off = jf_io.read_header(path)
+    assert header["format"] == "binary/sorted" and header["size"] >= 2 * 45275
+    k, lo, hi, cnt = jf_io.read_index(path)                          # (our own matrix: the same records, our order)
+    pos = jf_io.jf_positions(header["matrix1"]["columns"], 62, lo) & np.uint64(header["size"] - 1)
+    assert (np.diff(pos.astype(np.int64)) >= 0).all()
+    rheader, roff = jf_io.read_header(real)
+    again = str(tmp_path / "as_jellyfish.jf")
+    jf_io.write_jellyfish_index(again, 31, lo, None, cnt, header=rheader)
+    _, aoff = jf_io.read_header(again)
+    assert open(again, "rb").read()[aoff:] == open(real, "rb").read()[roff:]
+    # ... and the records themselves are the real file's
+    monkeypatch.delenv("KDF_JF_FORMAT")
+    _, jlo, _, jcnt = jf_io.read_index(real)
+    o = np.argsort(jlo)
+    np.testing.assert_array_equal(np.sort(lo), jlo[o]); np.testing.assert_array_equal(cnt[np.argsort(lo)], jcnt[o])
+
+
 @pytest.fixture(scope="module")
 def discovery(tmp_path_factory):
     from kmer_denovo_filter_amd.discovery.pipeline import (

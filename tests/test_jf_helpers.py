@@ -121,3 +121,71 @@ def test_index_is_streamed_block_by_block(tmp_path, oracle):
     np.testing.assert_array_equal(np.concatenate([g[3] for g in got]), cnt)
     k, rlo, rhi, rcnt = jf_io.read_index(p2)
     assert k == 47 and np.array_equal(rlo, lo) and np.array_equal(rhi, hi) and np.array_equal(rcnt, cnt)
+
+
+# ---- Jellyfish's own binary/sorted writer ----------------------------------------------------
+_FIXTURE_JF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "giab", "mini_ref.fa.k31.jf")
+
+
+def test_real_jellyfish_file_is_in_matrix_position_order():
+    """The record order of the reference's real Jellyfish file (its `count -m 31 -s 100M -C` of mini_ref.fa): ascending
+    hash position under the header's matrix1, equal positions in ascending key order -- the rule the writer follows."""
+    from kmer_denovo_filter_amd import jf_io
+    header, _ = jf_io.read_header(_FIXTURE_JF)
+    k, lo, hi, cnt = jf_io.read_index(_FIXTURE_JF)
+    assert (k, len(lo)) == (31, 45275)
+    m = header["matrix1"]
+    assert (m["c"], m["r"], 1 << m["r"]) == (62, 27, header["size"])
+    assert header["reprobes"] == jf_io.jf_reprobes(header["max_reprobe"])
+    pos = jf_io.jf_positions(m["columns"], 62, lo) & np.uint64(header["size"] - 1)
+    d = np.diff(pos.astype(np.int64))
+    assert (d >= 0).all()
+    ties = np.flatnonzero(d == 0)
+    assert len(ties) > 0 and (lo[ties] < lo[ties + 1]).all()
+    assert jf_io._gf2_rank(m["columns"], m["r"]) == m["r"]                               # (Jellyfish's matrix has full row rank too)
+
+
+def test_jellyfish_writer_gives_the_real_file_back_byte_for_byte(tmp_path):
+    """The fixture's records, shuffled, written under the fixture's own header: the same file."""
+    from kmer_denovo_filter_amd import jf_io
+    header, off = jf_io.read_header(_FIXTURE_JF)
+    k, lo, hi, cnt = jf_io.read_index(_FIXTURE_JF)
+    perm = np.random.default_rng(1).permutation(len(lo))
+    out = str(tmp_path / "again.jf")
+    jf_io.write_jellyfish_index(out, 31, lo[perm], None, cnt[perm], header=header)
+    want, got = open(_FIXTURE_JF, "rb").read(), open(out, "rb").read()
+    _, off2 = jf_io.read_header(out)
+    assert got[off2:] == want[off:]                                                     # every record, in Jellyfish's order
+    h2, _ = jf_io.read_header(out)
+    assert h2 == header                                                                 # (the JSON text may be spaced differently)
+
+
+@pytest.mark.parametrize("k", [5, 31, 32, 47, 63])
+def test_jellyfish_writer_with_its_own_matrix_round_trips(tmp_path, k):
+    from kmer_denovo_filter_amd import jf_io
+    rng = np.random.default_rng(k)
+    n = 700 if k == 5 else 5000
+    if k <= 32:
+        lo = np.unique(rng.integers(0, 1 << min(2 * k, 63), n, dtype=np.uint64)); hi = None
+    else:
+        lo = rng.integers(0, 1 << 63, n, dtype=np.uint64); hi = rng.integers(0, 1 << (2 * k - 64), n, dtype=np.uint64)
+    cnt = rng.integers(1, 1 << 32, len(lo), dtype=np.uint64).astype(np.uint32)
+    out = str(tmp_path / "own.jf")
+    jf_io.write_jellyfish_index(out, k, lo, hi, cnt, cmdline=["count", "-m", str(k), "-C"])
+    header, off = jf_io.read_header(out)
+    assert header["format"] == "binary/sorted" and header["canonical"] and off % 8 == 0
+    m = header["matrix1"]
+    assert m["c"] == 2 * k and (1 << m["r"]) == header["size"] >= 2 * len(lo)
+    assert jf_io._gf2_rank(m["columns"], m["r"]) == min(m["r"], 2 * k)
+    k2, rlo, rhi, rcnt = jf_io.read_index(out, expect_k=k)
+    pos = jf_io.jf_positions(m["columns"], 2 * k, rlo, rhi) & np.uint64(header["size"] - 1)
+    assert (np.diff(pos.astype(np.int64)) >= 0).all()
+    key = lambda a, b: sorted(zip((b if b is not None else np.zeros(len(a), np.uint64)).tolist(), a.tolist()))
+    o_w = np.lexsort((lo, hi)) if hi is not None else np.argsort(lo)
+    o_r = np.lexsort((rlo, rhi))
+    np.testing.assert_array_equal(rlo[o_r], lo[o_w]); np.testing.assert_array_equal(rcnt[o_r], cnt[o_w])
+    if hi is not None:
+        np.testing.assert_array_equal(rhi[o_r], hi[o_w])
+    again = str(tmp_path / "own2.jf")                                                   # deterministic: same input, same bytes
+    jf_io.write_jellyfish_index(again, k, lo, hi, cnt, cmdline=["count", "-m", str(k), "-C"])
+    assert open(again, "rb").read() == open(out, "rb").read()
