@@ -100,7 +100,10 @@ int kdf_flush(kdf_engine *h);
  *            "defer" (1 default; 0: every count call ends with a flush), "defer_max_bytes" (budget of the ring of
  *            partitioned entries, 0 = 40 % of the device's memory), "l1_positions" (size from which the pending
  *            stream of small batches is partitioned, default 2^30), "l1_direct_positions" (batches from this size on
- *            are partitioned where they lie, default 2^28);
+ *            are partitioned where they lie, default 2^28); "fused_dump" (0 default; 1: kdf_export_ge_dev with min_count >= 1
+ *            called while partition passes are pending is written by the flush that applies them -- kernel C dumps every
+ *            bucket it holds -- instead of by a pass over the table afterwards; falls back to that pass when a bucket
+ *            overflowed, was split as heavy, or a counter saturated; env KDF_FUSED_DUMP=1 sets the default);
  *            "hash_shift" (0..8, empty table only: the home slot ignores that many top hash bits -- the table of
  *            an OWNER rank of the multi-GPU merge, see kdf_add_pairs_multi_dev; such an engine counts through the
  *            direct kernels only); "merge_min_pairs" (below this many pairs kdf_add_pairs* skips the bucket merge);
@@ -112,7 +115,7 @@ int kdf_flush(kdf_engine *h);
  *            KDF_C1 (coarse bits of the partition), KDF_PIECE_FILL (how full the pieces are planned, default 0.98)
  *   stats    "binned_passes" (partition passes), "flushes" (kernel C launches), "pending_passes",
  *            "pending_positions", "ring_bytes", "replayed_buckets", "heavy_buckets" (buckets of skewed flushes that
- *            were shared by several workgroups), "log2cap", "bucket_bits", "hash_shift", "defer",
+ *            were shared by several workgroups), "log2cap", "bucket_bits", "hash_shift", "defer", "fused_dump", "fused_dumps" (dumps written by a flush),
  *            "last_count_path" (0 direct / 1 binned / 3 sieve), "last_merge_path" (1 LDS bucket
  *            merge, 2 global atomics); "trash0" .. "trash63" (phase cycle sums of -DKB_TIMING variant builds) */
 int kdf_set_option(kdf_engine *h, const char *name, int64_t value);

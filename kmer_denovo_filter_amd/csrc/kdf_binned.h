@@ -128,6 +128,7 @@ struct KbPlan {
     uint32_t n_pass;        // pending passes kernel C applies (1 .. KB_MAX_PASS)
     uint32_t group;         // G: slabs per group
     uint32_t n_groups, n_slabs;
+    uint32_t dump_min;      // the DUMP instantiations of kernel C (insert mode) also dump every slot with count >= dump_min >= 1 while they hold the bucket (KbScratch::dump_*)
 };
 
 // One partitioned pass in the ring (device resident, written by kb_binfirst_kernel).  Pieces are numbered BIN-MAJOR: the
@@ -167,6 +168,9 @@ struct KbScratch {
     uint64_t *hv_khi;
     uint32_t *hv_cnt;
     uint64_t *trash;                // [64] words nobody reads: where the pipelined piece sort stores when it has nothing to store
+    // `dump -L` fused into the flush (KbPlan::dump_min): keys (as KEYS, not stored forms) and counts go out through
+    // ctl->cursor, one reservation per bucket; nothing is written at or past dump_cap
+    uint64_t *dump_lo, *dump_hi; uint32_t *dump_cnt; unsigned long long dump_cap;
 };
 #ifndef KB_HV_MAX
 #define KB_HV_MAX    64u                             // heavy buckets split per flush (further ones are processed the ordinary way)
@@ -1167,7 +1171,7 @@ __device__ __forceinline__ void kb_probe_wide_wave(uint64_t *tlo, uint64_t *thi,
 #define KB_C_LDS_T(KW, BB, CT_, RUNS_) (((size_t)8 * (KW) + 4) * ((size_t)1 << (BB)) + (2 + 32 + (RUNS_)) * 4 + (size_t)(RUNS_) * 8 + ((KW) == 2 ? (size_t)(RUNS_) * 4 : 0) \
                           + KB_C_QCAPT(KW, CT_) * ((KW) == 2 ? 18 : 10) + 16 + ((RUNS_) + 4) * 4 + KB_RI_LDS_BYTES)
 #define KB_C_LDS(KW, BB) KB_C_LDS_T(KW, BB, KB_C_CTB(KW, (BB) > KB_BB_SMALL(KW)), KB_C_RUNS_T(KW, (BB) > KB_BB_SMALL(KW)))
-template <int KW, int MODE, int VAR, bool BIG = false>
+template <int KW, int MODE, int VAR, bool BIG = false, bool DUMP = false>
 __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_eu(BIG ? 4 : KB_C_WPE, BIG ? 4 : KB_C_WPE))) void kb_bucket_kernel(
     KbPlan plan, KbScratch s, KdfTable t, KdfCtl *ctl, int table_nonempty)
 {
@@ -1533,6 +1537,7 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
     }
     if (failed) atomicOr(&sh_failed, 1u);
     if (claimed) atomicAdd(&sh_claimed, claimed);
+    if (DUMP && threadIdx.x == 0) wsum[0] = 0;               // (the fused dump's counter; the scans are over)
     __syncthreads();
     if (sh_failed) {
         // leave the bucket as it was in HBM; flag it for replay.  A lazily
@@ -1556,6 +1561,29 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
     // two slots per lane and step: 16-byte LDS reads and HBM stores for the keys, 8-byte ones for the counts
     // (slot0 is a multiple of B, B is even: everything stays aligned)
     if (KB_ABL(plan, 512)) return;                                         // (ablation 512: no write-back -- timing only)
+    // DUMP: `dump -L dump_min` while the bucket is here.  The last flush before a dump sees every key's final count (every
+    // flush rewrites every bucket), so the separate pass over the table -- 6.4 GB for the bench's 2^29 slots, 1.4 ms -- is
+    // saved.  A thread counts what it keeps among the slot pairs it is about to write back, the waves add up in LDS, ONE
+    // global atomic per bucket reserves the range -- issued BEFORE the write-back, whose stores go out under its latency --
+    // and the kept slots go out as (key, count) after it.  Buckets that failed or were left to the heavy-bucket kernels
+    // never get here, and a counter that wrapped in this flush (it saturates: its LDS word is not its value) is flagged:
+    // the host then dumps the usual way.
+    uint32_t d_n = 0, d_inc = 0, d_wb = 0; unsigned long long d_base = 0;
+    if constexpr (DUMP) {
+        const uint32_t dm = plan.dump_min;
+        for (uint32_t i = threadIdx.x; i < B / 2; i += CT) {
+            const uint2 c2 = ((const uint2 *)tcnt)[i];
+            d_n += (c2.x >= dm) + (c2.y >= dm);
+        }
+        d_inc = d_n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(d_inc, o); if ((int)(threadIdx.x & 63) >= o) d_inc += v; }
+        if ((threadIdx.x & 63) == 63 && d_inc) d_wb = atomicAdd(&wsum[0], d_inc);
+        d_wb = __shfl(d_wb, 63);
+        __syncthreads();
+        if (threadIdx.x == 0) { const uint32_t tot = wsum[0]; if (tot) d_base = atomicAdd(&ctl->cursor, (unsigned long long)tot); }
+    }
+    bool wrapped = false;
     for (uint32_t i = threadIdx.x; i < B / 2; i += CT) {
         if constexpr (MODE == KB_MODE_INSERT) {
             ((ulonglong2 *)(t.lo + slot0))[i] = ((const ulonglong2 *)tlo)[i];
@@ -1564,13 +1592,39 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
         uint2 c2 = ((const uint2 *)tcnt)[i];
         if (table_nonempty) {
             const uint2 o = ((const uint2 *)(t.cnt + slot0))[i];
-            if (c2.x < o.x) c2.x = 0xFFFFFFFFu;
-            if (c2.y < o.y) c2.y = 0xFFFFFFFFu;
+            if (c2.x < o.x) { c2.x = 0xFFFFFFFFu; wrapped = true; }
+            if (c2.y < o.y) { c2.y = 0xFFFFFFFFu; wrapped = true; }
         }
         ((uint2 *)(t.cnt + slot0))[i] = c2;
     }
     if (threadIdx.x == 0 && sh_claimed)
         atomicAdd(&ctl->distinct[(bucket % KDF_SHARDS) * 16], (unsigned long long)sh_claimed);
+    if constexpr (DUMP) {
+        if (wrapped) atomicAdd(&s.totals[8], 1ull);            // (the dump is not to be trusted: see above)
+        if (threadIdx.x == 0) *(unsigned long long *)(wsum + 2) = d_base;
+        __syncthreads();
+        if (d_n) {
+            const uint32_t dm = plan.dump_min;
+            unsigned long long pos = *(const unsigned long long *)(wsum + 2) + d_wb + (d_inc - d_n);
+            for (uint32_t i = threadIdx.x; i < B / 2; i += CT) {
+                const uint2 c2 = ((const uint2 *)tcnt)[i];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const uint32_t cv = e ? c2.y : c2.x;
+                    if (cv >= dm) {
+                        if (pos < s.dump_cap) {
+                            uint64_t hi = 0;
+                            if constexpr (KW == 2) hi = thi[2 * i + e];
+                            s.dump_lo[pos] = kdf_key_lo(tlo[2 * i + e], hi);
+                            if constexpr (KW == 2) if (s.dump_hi) s.dump_hi[pos] = hi;
+                            if (s.dump_cnt) s.dump_cnt[pos] = cv;
+                        }
+                        ++pos;
+                    }
+                }
+            }
+        }
+    }
 #ifdef KB_TIMING
     KB_T(s.trash, 39);                                        // write-back issued
     if (threadIdx.x == 0) atomicAdd((unsigned long long *)&s.trash[8 + 40], 1ull);

@@ -489,6 +489,15 @@ struct kdf_engine {
     int opt_force_path = 0;                          // 0 auto, 1 direct, 2 binned, 4 sieve only (count --if)
     int opt_defer = 1;                               // 1: kernel C is deferred over the pending passes; 0: every count call ends with a flush
     uint64_t opt_defer_max_bytes = 0;                // budget of the entry ring (0: 40 % of the device's memory)
+    // 1: a dump (min_count >= 1, caller-sized device buffers) asked for while passes are pending is written by the flush itself
+    // -- kernel C holds every bucket anyway (kb_bucket_kernel<.., DUMP>).  Off by default: at bench size the step is 13.1 ->
+    // 12.6 ms (the 1.4 ms table pass of the dump saved), but kernel C takes 0.9 ms longer for it (two barriers and a global
+    // reservation per bucket); option "fused_dump" / env KDF_FUSED_DUMP=1
+    int opt_fused_dump = [] { const char *e = getenv("KDF_FUSED_DUMP"); return e ? atoi(e) != 0 : 0; }();
+    // the request a dump hands to the LAST flush before it (fuse_min > 0), and what came of it
+    uint32_t fuse_min = 0; uint64_t *fuse_lo = nullptr, *fuse_hi = nullptr; uint32_t *fuse_cnt = nullptr; uint64_t fuse_cap = 0;
+    bool fuse_done = false; uint64_t fuse_n = 0;
+    uint64_t stat_fused_dumps = 0;
     uint64_t opt_l1_positions = 1ull << 30;          // pending-stream size from which it is partitioned
     uint64_t opt_l1_direct_positions = 1ull << 28;   // batches from this size on are partitioned where they lie (no copy)
     // double-buffered feeding (kdf_upload_reads_async / kdf_count_uploaded): two device staging slots filled on a copy
@@ -787,7 +796,9 @@ static int kb_set_lds_attrs(kdf_engine *h, size_t a, size_t b, size_t c, size_t 
     HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_INSERT, V, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c)); \
     HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_FILTERED, V, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c)); \
     HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_INSERT, V, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cbig)); \
-    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_FILTERED, V, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cbig));
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_FILTERED, V, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cbig)); \
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_INSERT, V, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c)); \
+    HIPCHK(h, hipFuncSetAttribute((const void *)(kb_bucket_kernel<KW, KB_MODE_INSERT, V, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cbig));
     KB_SETV(1)
     KB_SETV(2)
 #undef KB_SETV
@@ -1005,6 +1016,15 @@ static int kb_flush_ring(kdf_engine *h) {
     KbPlan plan = h->pend_plan;
     plan.n_pass = h->n_pass; plan.dbg = h->opt_debug_flags;
     plan.log2cap = h->t.log2cap; plan.bucket_bits = h->t.bucket_bits;
+    // a dump is waiting for this flush: kernel C writes it out of the buckets it holds (the request is taken: a second
+    // flush of the same call must not dump again)
+    const uint32_t fuse_min = filtered ? 0u : h->fuse_min;
+    h->fuse_min = 0; h->fuse_done = false;
+    if (fuse_min) {
+        plan.dump_min = fuse_min;
+        s.dump_lo = h->fuse_lo; s.dump_hi = h->fuse_hi; s.dump_cnt = h->fuse_cnt; s.dump_cap = h->fuse_cap;
+        HIPCHK(h, hipMemsetAsync(&h->ctl->cursor, 0, 8, h->stream));
+    }
     plan.sub_bits = (h->t.log2cap - h->t.bucket_bits) - plan.c1 - plan.c2;       // a table that grew since the partition: more sub-buckets
     const uint64_t nb_table = 1ull << (plan.c1 + plan.c2 + plan.sub_bits);
     const size_t failed_bytes = (size_t)((nb_table + 31) / 32) * 4;
@@ -1027,10 +1047,11 @@ static int kb_flush_ring(kdf_engine *h) {
         constexpr int KW = decltype(KWc)::value;
         const size_t lds_c = KB_C_LDS(KW, plan.bucket_bits);
         const bool big = plan.bucket_bits > KB_BB_SMALL(KW);
-#define KB_LV(M, V) do { if (big) hipLaunchKernelGGL((kb_bucket_kernel<KW, M, V, true>), dim3((unsigned)nb_table), dim3(KB_C_CT_BIG), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty); \
-                         else hipLaunchKernelGGL((kb_bucket_kernel<KW, M, V, false>), dim3((unsigned)nb_table), dim3(KB_C_CT(KW)), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty); } while (0)
-        if (filtered) { if (skewed) KB_LV(KB_MODE_FILTERED, 2); else KB_LV(KB_MODE_FILTERED, 1); }
-        else { if (skewed) KB_LV(KB_MODE_INSERT, 2); else KB_LV(KB_MODE_INSERT, 1); }
+#define KB_LV(M, V, D) do { if (big) hipLaunchKernelGGL((kb_bucket_kernel<KW, M, V, true, D>), dim3((unsigned)nb_table), dim3(KB_C_CT_BIG), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty); \
+                         else hipLaunchKernelGGL((kb_bucket_kernel<KW, M, V, false, D>), dim3((unsigned)nb_table), dim3(KB_C_CT(KW)), lds_c, h->stream, plan, s, h->t, h->ctl, nonempty); } while (0)
+        if (filtered) { if (skewed) KB_LV(KB_MODE_FILTERED, 2, false); else KB_LV(KB_MODE_FILTERED, 1, false); }
+        else if (fuse_min) { if (skewed) KB_LV(KB_MODE_INSERT, 2, true); else KB_LV(KB_MODE_INSERT, 1, true); }
+        else { if (skewed) KB_LV(KB_MODE_INSERT, 2, false); else KB_LV(KB_MODE_INSERT, 1, false); }
 #undef KB_LV
         return 0;
     });
@@ -1058,7 +1079,11 @@ static int kb_flush_ring(kdf_engine *h) {
     }
     HIPCHK(h, hipMemcpyAsync(h->kb_totals_host, s.totals, 16 * 8, hipMemcpyDeviceToHost, h->stream));
     bool full = false;
-    if ((rc = ctl_sync(h, &full))) return rc;
+    uint64_t cursor = 0;
+    if ((rc = ctl_sync(h, &full, &cursor))) return rc;
+    // the fused dump is whole only if every bucket went through kernel C's write-back (none failed, none was left to the
+    // heavy-bucket kernels); otherwise the caller dumps from the table as usual
+    if (fuse_min && h->kb_totals_host[2] == 0 && h->kb_totals_host[4] == 0 && h->kb_totals_host[8] == 0) { h->fuse_done = true; h->fuse_n = cursor; h->stat_fused_dumps++; }
     h->stat_flushes++;
     h->lazy_empty = false;
     h->stat_heavy_buckets += h->kb_totals_host[4];
@@ -1168,8 +1193,10 @@ static int l1_append(kdf_engine *h, const uint64_t *d_packed, const uint64_t *d_
 }
 
 // everything pending (the concatenated small batches, the partitioned passes) goes into the table
-static int pending_flush(kdf_engine *h) {
+static int pending_flush(kdf_engine *h, bool fuse = false) {
     int rc;
+    const uint32_t want_fuse = fuse ? h->fuse_min : 0u;
+    h->fuse_min = 0; h->fuse_done = false;                     // (only the LAST flush below may dump: earlier ones see counts that are not final)
     if (h->l1_tiles) {
         const uint64_t n = h->l1_tiles * KDF_TILE;
         h->l1_tiles = 0;
@@ -1177,7 +1204,10 @@ static int pending_flush(kdf_engine *h) {
         else rc = direct_insert(h, h->l1_packed, h->l1_mask, n);
         if (rc) return rc;
     }
-    return kb_flush_ring(h);
+    h->fuse_min = want_fuse;
+    rc = kb_flush_ring(h);
+    h->fuse_min = 0;
+    return rc;
 }
 // ... or is forgotten (kdf_clear)
 static int pending_drop(kdf_engine *h) {
@@ -1816,7 +1846,12 @@ int kdf_query(kdf_engine *h, const uint64_t *keys_lo, const uint64_t *keys_hi, u
 
 static int export_pass(kdf_engine *h, uint32_t min_count, bool write, uint64_t *olo, uint64_t *ohi,
                        uint32_t *ocnt, uint64_t out_cap, uint64_t *n_out) {
-    { int rcf = pending_flush(h); if (rcf) return rcf; }
+    // passes pending: the flush that applies them holds every bucket of the table in LDS once -- it writes the dump too
+    // (kb_bucket_kernel, KbPlan::dump_min) unless a bucket took another way (overflow replay, heavy-bucket split)
+    const bool fuse = write && min_count >= 1 && h->opt_fused_dump && !h->filter_mode && olo && (h->kw == 1 || ohi) && (h->n_pass > 0 || h->l1_tiles > 0);
+    if (fuse) { h->fuse_min = min_count; h->fuse_lo = olo; h->fuse_hi = ohi; h->fuse_cnt = ocnt; h->fuse_cap = out_cap; }
+    { int rcf = pending_flush(h, fuse); if (rcf) return rcf; }
+    if (fuse && h->fuse_done) { h->fuse_done = false; *n_out = h->fuse_n; return KDF_OK; }
     { int rc0 = materialize(h); if (rc0) return rc0; }
     HIPCHK(h, hipMemsetAsync(h->ctl->tally, 0, sizeof(h->ctl->tally) + 8, h->stream));   // tally[] + cursor
     const uint64_t waves = (h->cap + KDF_EXPORT_ROWS * 64 - 1) / (KDF_EXPORT_ROWS * 64);
@@ -2153,6 +2188,7 @@ int kdf_set_option(kdf_engine *h, const char *name, int64_t value) {
     }
     else if (n == "defer") h->opt_defer = value != 0;
     else if (n == "defer_max_bytes") h->opt_defer_max_bytes = (uint64_t)value;
+    else if (n == "fused_dump") h->opt_fused_dump = value != 0;
     else if (n == "l1_positions") h->opt_l1_positions = (uint64_t)std::max<int64_t>(value, KDF_TILE);
     else if (n == "l1_direct_positions") h->opt_l1_direct_positions = (uint64_t)std::max<int64_t>(value, 0);
     else if (n == "sieve_bits") h->opt_sieve_bits = (int)value;
@@ -2174,6 +2210,8 @@ int kdf_get_stat(kdf_engine *h, const char *name, int64_t *value) {
     else if (n == "last_count_path") *value = h->last_path;
     else if (n == "last_merge_path") *value = h->last_merge_path;
     else if (n == "heavy_buckets") *value = (int64_t)h->stat_heavy_buckets;
+    else if (n == "fused_dumps") *value = (int64_t)h->stat_fused_dumps;
+    else if (n == "fused_dump") *value = h->opt_fused_dump;
     else if (n == "hash_shift") *value = h->opt_hash_shift;
     else if (n == "log2cap") *value = h->t.log2cap;
     else if (n == "bucket_bits") *value = h->t.bucket_bits;

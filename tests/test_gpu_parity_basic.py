@@ -448,3 +448,79 @@ def test_heavy_buckets_are_split_and_stay_exact(oracle, k):
             np.testing.assert_array_equal(e.query(lo[::7], hi[::7] if k > 32 else None), cnt[::7])
             if hint == 1 << 22 and batches == 1:
                 assert e.get_stat("heavy_buckets") > 0, "the skewed instantiation did not split any bucket: the test does not reach the code"
+
+
+@pytest.mark.parametrize("k", [31, 63])
+def test_dump_fused_into_the_flush_equals_the_table_dump(oracle, k):
+    """`jellyfish count` followed by `dump -L n` (discovery/pipeline.py:114-196): with partition passes pending, the flush that
+    applies them can write the dump out of the buckets it holds (kb_bucket_kernel<.., DUMP>; option fused_dump).  Fused == dump from
+    the table (fused_dump 0, the default) == oracle, for several thresholds, into a fresh table and into a live one (counts from an earlier
+    flush), with the heavy-bucket split taking the dump back to the table pass, and with a buffer that is too small."""
+    import torch
+    from kmer_denovo_filter_amd import KmerEngine, ReadStream
+    rng = np.random.default_rng(4100 + k)
+    genome = rng.integers(0, 4, 40000).astype(np.uint8)
+    first = rand_reads(rng, 6000, k, 260, genome=genome)
+    second = rand_reads(rng, 5000, k, 260, genome=genome) + ["ACGT" * 70, "N" * 80, ""]
+    wide = k > 32
+
+    def dump(e, min_count, cap):
+        lo = torch.zeros(max(cap, 1), dtype=torch.int64, device="cuda:0"); cnt = torch.zeros(max(cap, 1), dtype=torch.int32, device="cuda:0")
+        hi = torch.zeros(max(cap, 1), dtype=torch.int64, device="cuda:0") if wide else None
+        torch.cuda.synchronize()
+        n = e.export_ge_dev(min_count, lo.data_ptr(), hi.data_ptr() if wide else None, cnt.data_ptr(), cap, sorted_=True)
+        glo = lo[:n].cpu().numpy().view(np.uint64); gcnt = cnt[:n].cpu().numpy().view(np.uint32)
+        ghi = hi[:n].cpu().numpy().view(np.uint64) if wide else np.zeros(n, np.uint64)
+        return glo, ghi, gcnt
+
+    def want(reads, min_count):
+        _, (lo, hi, cnt) = oracle_sorted(oracle, k, reads)
+        keep = cnt >= min_count
+        return lo[keep], hi[keep], cnt[keep]
+
+    for min_count in (1, 2, 3):
+        for fused in (1, 0):
+            with KmerEngine(k, capacity_hint=1 << 20) as e:
+                e.set_option("force_path", 2); e.set_option("fused_dump", fused)
+                for i in range(3):
+                    e.count(ReadStream.from_strings(first[i::3]))
+                assert e.get_stat("pending_passes") == 3
+                got = dump(e, min_count, 1 << 21)
+                assert e.get_stat("pending_passes") == 0 and e.get_stat("flushes") == 1
+                assert e.get_stat("fused_dumps") == fused
+                for g, w in zip(got, want(first, min_count)):
+                    np.testing.assert_array_equal(g, w)
+                # more reads into the LIVE table (kernel C reads the buckets back and adds), dumped again
+                e.count(ReadStream.from_strings(second))
+                got = dump(e, min_count, 1 << 21)
+                assert e.get_stat("fused_dumps") == 2 * fused
+                for g, w in zip(got, want(first + second, min_count)):
+                    np.testing.assert_array_equal(g, w)
+                # nothing pending: the table pass
+                got = dump(e, min_count + 1, 1 << 21)
+                assert e.get_stat("fused_dumps") == 2 * fused
+                for g, w in zip(got, want(first + second, min_count + 1)):
+                    np.testing.assert_array_equal(g, w)
+    # a buffer that is too small: the error the table dump gives, nothing written past the end
+    with KmerEngine(k, capacity_hint=1 << 20) as e:
+        e.set_option("force_path", 2); e.set_option("fused_dump", 1)
+        e.count(ReadStream.from_strings(first))
+        guard = torch.full((1000 + 64,), -7, dtype=torch.int64, device="cuda:0"); cnt = torch.zeros(1000, dtype=torch.int32, device="cuda:0")
+        hi = torch.zeros(1000, dtype=torch.int64, device="cuda:0") if wide else None
+        torch.cuda.synchronize()
+        with pytest.raises(Exception, match="room for 1000"):
+            e.export_ge_dev(1, guard.data_ptr(), hi.data_ptr() if wide else None, cnt.data_ptr(), 1000)
+        assert bool((guard[1000:] == -7).all())
+        got = dump(e, 1, 1 << 21)                                 # (the table is intact)
+        for g, w in zip(got, want(first, 1)):
+            np.testing.assert_array_equal(g, w)
+    # heavy buckets (a homopolymer flood: the skew instantiation leaves them to the heavy-bucket kernels): no fused dump, same result
+    flood = first[:2000] + ["A" * 400] * 6000
+    with KmerEngine(k, capacity_hint=1 << 20) as e:
+        e.set_option("force_path", 2); e.set_option("fused_dump", 1)
+        e.count(ReadStream.from_strings(flood)); e.flush()        # (the first flush of an engine learns the skew)
+        e.count(ReadStream.from_strings(flood))
+        got = dump(e, 2, 1 << 21)
+        assert e.get_stat("heavy_buckets") > 0 and e.get_stat("fused_dumps") == 0
+        for g, w in zip(got, want(flood + flood, 2)):
+            np.testing.assert_array_equal(g, w)
