@@ -103,7 +103,7 @@ int kdf_flush(kdf_engine *h);
  *            are partitioned where they lie, default 2^28); "fused_dump" (0 default; 1: kdf_export_ge_dev with min_count >= 1
  *            called while partition passes are pending is written by the flush that applies them -- kernel C dumps every
  *            bucket it holds -- instead of by a pass over the table afterwards; falls back to that pass when a bucket
- *            overflowed, was split as heavy, or a counter saturated; env KDF_FUSED_DUMP=1 sets the default);
+ *            overflowed or was split as heavy; env KDF_FUSED_DUMP=1 sets the default);
  *            "hash_shift" (0..8, empty table only: the home slot ignores that many top hash bits -- the table of
  *            an OWNER rank of the multi-GPU merge, see kdf_add_pairs_multi_dev; such an engine counts through the
  *            direct kernels only); "merge_min_pairs" (below this many pairs kdf_add_pairs* skips the bucket merge);

@@ -1561,29 +1561,6 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
     // two slots per lane and step: 16-byte LDS reads and HBM stores for the keys, 8-byte ones for the counts
     // (slot0 is a multiple of B, B is even: everything stays aligned)
     if (KB_ABL(plan, 512)) return;                                         // (ablation 512: no write-back -- timing only)
-    // DUMP: `dump -L dump_min` while the bucket is here.  The last flush before a dump sees every key's final count (every
-    // flush rewrites every bucket), so the separate pass over the table -- 6.4 GB for the bench's 2^29 slots, 1.4 ms -- is
-    // saved.  A thread counts what it keeps among the slot pairs it is about to write back, the waves add up in LDS, ONE
-    // global atomic per bucket reserves the range -- issued BEFORE the write-back, whose stores go out under its latency --
-    // and the kept slots go out as (key, count) after it.  Buckets that failed or were left to the heavy-bucket kernels
-    // never get here, and a counter that wrapped in this flush (it saturates: its LDS word is not its value) is flagged:
-    // the host then dumps the usual way.
-    uint32_t d_n = 0, d_inc = 0, d_wb = 0; unsigned long long d_base = 0;
-    if constexpr (DUMP) {
-        const uint32_t dm = plan.dump_min;
-        for (uint32_t i = threadIdx.x; i < B / 2; i += CT) {
-            const uint2 c2 = ((const uint2 *)tcnt)[i];
-            d_n += (c2.x >= dm) + (c2.y >= dm);
-        }
-        d_inc = d_n;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(d_inc, o); if ((int)(threadIdx.x & 63) >= o) d_inc += v; }
-        if ((threadIdx.x & 63) == 63 && d_inc) d_wb = atomicAdd(&wsum[0], d_inc);
-        d_wb = __shfl(d_wb, 63);
-        __syncthreads();
-        if (threadIdx.x == 0) { const uint32_t tot = wsum[0]; if (tot) d_base = atomicAdd(&ctl->cursor, (unsigned long long)tot); }
-    }
-    bool wrapped = false;
     for (uint32_t i = threadIdx.x; i < B / 2; i += CT) {
         if constexpr (MODE == KB_MODE_INSERT) {
             ((ulonglong2 *)(t.lo + slot0))[i] = ((const ulonglong2 *)tlo)[i];
@@ -1592,20 +1569,44 @@ __global__ __launch_bounds__(KB_C_CTB(KW, BIG)) __attribute__((amdgpu_waves_per_
         uint2 c2 = ((const uint2 *)tcnt)[i];
         if (table_nonempty) {
             const uint2 o = ((const uint2 *)(t.cnt + slot0))[i];
-            if (c2.x < o.x) { c2.x = 0xFFFFFFFFu; wrapped = true; }
-            if (c2.y < o.y) { c2.y = 0xFFFFFFFFu; wrapped = true; }
+            if (c2.x < o.x || c2.y < o.y) {
+                if (c2.x < o.x) c2.x = 0xFFFFFFFFu;
+                if (c2.y < o.y) c2.y = 0xFFFFFFFFu;
+                if constexpr (DUMP) ((uint2 *)tcnt)[i] = c2;     // (the dump below reads the counts from LDS)
+            }
         }
         ((uint2 *)(t.cnt + slot0))[i] = c2;
     }
     if (threadIdx.x == 0 && sh_claimed)
         atomicAdd(&ctl->distinct[(bucket % KDF_SHARDS) * 16], (unsigned long long)sh_claimed);
+    // DUMP: `dump -L dump_min` while the bucket is here.  The last flush before a dump sees every key's final count (every
+    // flush rewrites every bucket), so the separate pass over the table -- 6.4 GB for the bench's 2^29 slots, 1.4 ms -- is
+    // saved.  A thread counts what it keeps among the slot pairs it has just written back (its own LDS words: no barrier),
+    // the waves add up in LDS, ONE global atomic per bucket reserves the range, and the kept slots go out as (key, count).
+    // Buckets that failed or were left to the heavy-bucket kernels never get here: the host then dumps the usual way.
+    // (Measured the same: the reservation issued BEFORE the write-back, to hide its round trip under those stores,
+    // profiles/r03b_fused_dump.txt.)
     if constexpr (DUMP) {
-        if (wrapped) atomicAdd(&s.totals[8], 1ull);            // (the dump is not to be trusted: see above)
-        if (threadIdx.x == 0) *(unsigned long long *)(wsum + 2) = d_base;
+        const uint32_t dm = plan.dump_min;
+        uint32_t n = 0;
+        for (uint32_t i = threadIdx.x; i < B / 2; i += CT) {
+            const uint2 c2 = ((const uint2 *)tcnt)[i];
+            n += (c2.x >= dm) + (c2.y >= dm);
+        }
+        uint32_t inc = n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if ((int)(threadIdx.x & 63) >= o) inc += v; }
+        uint32_t wb = 0;
+        if ((threadIdx.x & 63) == 63 && inc) wb = atomicAdd(&wsum[0], inc);
+        wb = __shfl(wb, 63);
         __syncthreads();
-        if (d_n) {
-            const uint32_t dm = plan.dump_min;
-            unsigned long long pos = *(const unsigned long long *)(wsum + 2) + d_wb + (d_inc - d_n);
+        if (threadIdx.x == 0) {
+            const uint32_t tot = wsum[0];
+            *(unsigned long long *)(wsum + 2) = tot ? atomicAdd(&ctl->cursor, (unsigned long long)tot) : 0ull;
+        }
+        __syncthreads();
+        if (n) {
+            unsigned long long pos = *(const unsigned long long *)(wsum + 2) + wb + (inc - n);
             for (uint32_t i = threadIdx.x; i < B / 2; i += CT) {
                 const uint2 c2 = ((const uint2 *)tcnt)[i];
 #pragma unroll

@@ -1083,7 +1083,7 @@ static int kb_flush_ring(kdf_engine *h) {
     if ((rc = ctl_sync(h, &full, &cursor))) return rc;
     // the fused dump is whole only if every bucket went through kernel C's write-back (none failed, none was left to the
     // heavy-bucket kernels); otherwise the caller dumps from the table as usual
-    if (fuse_min && h->kb_totals_host[2] == 0 && h->kb_totals_host[4] == 0 && h->kb_totals_host[8] == 0) { h->fuse_done = true; h->fuse_n = cursor; h->stat_fused_dumps++; }
+    if (fuse_min && h->kb_totals_host[2] == 0 && h->kb_totals_host[4] == 0) { h->fuse_done = true; h->fuse_n = cursor; h->stat_fused_dumps++; }
     h->stat_flushes++;
     h->lazy_empty = false;
     h->stat_heavy_buckets += h->kb_totals_host[4];
