@@ -1023,7 +1023,7 @@ static int kb_flush_ring(kdf_engine *h) {
     if (fuse_min) {
         plan.dump_min = fuse_min;
         s.dump_lo = h->fuse_lo; s.dump_hi = h->fuse_hi; s.dump_cnt = h->fuse_cnt; s.dump_cap = h->fuse_cap;
-        HIPCHK(h, hipMemsetAsync(&h->ctl->cursor, 0, 8, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->ctl->tally, 0, sizeof(h->ctl->tally) + 8, h->stream));   // tally[] + cursor: ctl_sync reports their sum (a kdf_count_ge before this leaves its tally behind)
     }
     plan.sub_bits = (h->t.log2cap - h->t.bucket_bits) - plan.c1 - plan.c2;       // a table that grew since the partition: more sub-buckets
     const uint64_t nb_table = 1ull << (plan.c1 + plan.c2 + plan.sub_bits);

@@ -1,8 +1,11 @@
 #!/bin/bash
-# long randomised parity over the code of the second half of round 3 (pipelined piece sort, big buckets, wide heavy split)
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r3s2_fuzz
-(timeout -k 10 400 python scratch/fuzz_round2.py 41 330 1 > gpurun_out/r3s2_fuzz/s41.txt 2>&1; tail -2 gpurun_out/r3s2_fuzz/s41.txt) &
-(timeout -k 10 400 python scratch/fuzz_round2.py 42 330 3 > gpurun_out/r3s2_fuzz/s42.txt 2>&1; tail -2 gpurun_out/r3s2_fuzz/s42.txt) &
-(timeout -k 10 400 python scratch/fuzz_round2.py 43 330 10 > gpurun_out/r3s2_fuzz/s43.txt 2>&1; tail -2 gpurun_out/r3s2_fuzz/s43.txt) &
+# the fuzz tests, then a long randomised run (three processes) over the round-2/3 paths incl. the fused dump leg
+set -o pipefail
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r3s2_fuzz2; mkdir -p $O
+timeout -k 10 600 python -m pytest tests/test_gpu_fuzz.py -x -q -m gpu > $O/tests.log 2>&1; rc=$?; echo "fuzz tests rc=$rc"; tail -3 $O/tests.log
+[ $rc -ne 0 ] && exit 1
+(timeout -k 10 460 python scratch/fuzz_round2.py 41 400 1 > $O/s41.txt 2>&1; tail -1 $O/s41.txt) &
+(timeout -k 10 460 python scratch/fuzz_round2.py 42 400 6 > $O/s42.txt 2>&1; tail -1 $O/s42.txt) &
+(timeout -k 10 460 python scratch/fuzz_round2.py 43 400 20 > $O/s43.txt 2>&1; tail -1 $O/s43.txt) &
 wait
-grep -l "Error\|assert\|Traceback" gpurun_out/r3s2_fuzz/*.txt; echo done
+grep -l "Error\|assert\|Traceback" $O/*.txt; echo done

@@ -89,6 +89,7 @@ def round2_case(O, rng, scale, tag0):
         e.set_option("force_path", p); e.set_option("binned_max_positions", maxpos); e.set_option("debug_flags", skewvar)
         e.set_option("defer", defer); e.set_option("l1_positions", l1); e.set_option("l1_direct_positions", 4 * l1)
         e.set_option("binned_min_positions", int(rng.choice([1 << 10, 1 << 22])))
+        e.set_option("fused_dump", (len(reads) + k) % 2)     # `dump -L` written by the flush that applies the pending passes (not drawn from rng either)
 
     with KmerEngine(k, capacity_hint=hint) as e:
         opts(e)
@@ -106,6 +107,17 @@ def round2_case(O, rng, scale, tag0):
                     e.count_ge(1)
         else:
             e.count(ReadStream.from_strings(reads))
+        if len(lo):                                          # `dump -L n` into caller-sized device buffers, whatever is still pending
+            dthr = 1 + len(reads) % 3
+            dl = torch.zeros(len(lo), dtype=torch.int64, device="cuda:0"); dc = torch.zeros(len(lo), dtype=torch.int32, device="cuda:0")
+            dh = torch.zeros(len(lo), dtype=torch.int64, device="cuda:0") if wide else None
+            torch.cuda.synchronize()
+            nd = e.export_ge_dev(dthr, dl.data_ptr(), dh.data_ptr() if wide else None, dc.data_ptr(), len(lo), sorted_=True)
+            keep = cnt >= dthr
+            assert nd == int(keep.sum()), tag
+            assert np.array_equal(dl[:nd].cpu().numpy().view(np.uint64), lo[keep]) and np.array_equal(dc[:nd].cpu().numpy().view(np.uint32), cnt[keep]), tag
+            if wide:
+                assert np.array_equal(dh[:nd].cpu().numpy().view(np.uint64), hi[keep]), tag
         glo, ghi, gcnt = e.export_ge(0)
         assert np.array_equal(glo, lo) and np.array_equal(ghi, hi) and np.array_equal(gcnt, cnt), tag
         thr = int(rng.integers(1, 6))

@@ -482,11 +482,13 @@ def test_dump_fused_into_the_flush_equals_the_table_dump(oracle, k):
         for fused in (1, 0):
             with KmerEngine(k, capacity_hint=1 << 20) as e:
                 e.set_option("force_path", 2); e.set_option("fused_dump", fused)
-                for i in range(3):
-                    e.count(ReadStream.from_strings(first[i::3]))
+                e.count(ReadStream.from_strings(first[0::4]))
+                assert e.count_ge(1) > 0                          # (a tally left behind by an earlier read must not leak into the dump's size: the fuzz found that)
+                for i in range(1, 4):
+                    e.count(ReadStream.from_strings(first[i::4]))
                 assert e.get_stat("pending_passes") == 3
                 got = dump(e, min_count, 1 << 21)
-                assert e.get_stat("pending_passes") == 0 and e.get_stat("flushes") == 1
+                assert e.get_stat("pending_passes") == 0 and e.get_stat("flushes") == 2
                 assert e.get_stat("fused_dumps") == fused
                 for g, w in zip(got, want(first, min_count)):
                     np.testing.assert_array_equal(g, w)
